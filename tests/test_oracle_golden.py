@@ -1,0 +1,137 @@
+"""The CPU oracle (oracle/oracle_dense.cpp) against fixtures produced by the reference's own Python
+(tests/golden/make_golden.py).  This is what pins the oracle; everything else is checked against it."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.conftest import GOLDEN
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def dense_from_coo(z):
+    n = int(z["n"])
+    H = np.zeros((n, n))
+    H[z["H_row"], z["H_col"]] = z["H_val"]
+    return H
+
+
+@pytest.mark.parametrize("lin,as_wire", [("c1_lin_f64.npz", False), ("c1_lin_wire.npz", True)])
+def test_c1_per_edge_residuals_and_jacobians(lin, as_wire):
+    g = oracle.Graph.from_npz(load("c1_graph.npz"), as_wire=as_wire)
+    z = load(lin)
+    e, A, B = oracle.edge_eval(g)
+    assert e.shape[0] == 2123
+    np.testing.assert_allclose(e, z["edge_e"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(A, z["edge_A"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(B, z["edge_B"], rtol=0, atol=1e-11)
+
+
+@pytest.mark.parametrize("lin,as_wire", [("c1_lin_f64.npz", False), ("c1_lin_wire.npz", True)])
+def test_c1_linearisation_matches_reference_python(lin, as_wire):
+    g = oracle.Graph.from_npz(load("c1_graph.npz"), as_wire=as_wire)
+    z = load(lin)
+    H, b, err, idx = oracle.linearize(g, python_mode=True)
+    np.testing.assert_array_equal(idx, z["index_of_vertex"])
+    Href = dense_from_coo(z)
+    assert abs(err - float(z["err"])) <= 1e-9 * float(z["err"])
+    scale = np.abs(Href).max()
+    assert np.abs(H - Href).max() <= 1e-9 * scale
+    np.testing.assert_allclose(b, z["b"], rtol=0, atol=1e-9 * np.abs(z["b"]).max())
+    assert abs(H.sum() - float(z["H_sum"])) <= 1e-9 * abs(float(z["H_sum"]))
+    # the C++ restatement only differs in the sign of b and in not zeroing b at fixed vertices
+    H2, b2, err2, _ = oracle.linearize(g, python_mode=False)
+    assert err2 == err and np.array_equal(H2, H)
+    free = np.ones(len(b), bool); free[:3] = False          # vertex 0 is the fixed pose
+    np.testing.assert_allclose(b2[free], -b[free], rtol=0, atol=1e-9 * np.abs(b).max())
+    assert np.abs(b2[:3]).max() > 0                          # OptimizerCpu.h:137 leaves b untouched
+
+
+def test_c1_known_answers_from_survey():
+    z = load("c1_lin_f64.npz")
+    assert abs(float(z["err"]) - 114586.1496325) < 1e-6
+    assert abs(float(z["H_sum"]) - 44632078.198713) < 1e-5
+    assert abs(float(z["b"].sum()) - 90435.166569) < 1e-5
+    assert abs(float(z["H_trace"]) - 44747212.851129) < 1e-5
+    assert len(z["H_val"]) == 27242
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c"])
+def test_tiny_graphs(name):
+    z = load(name + ".npz")
+    g = oracle.Graph.from_npz(z)
+    e, A, B = oracle.edge_eval(g)
+    np.testing.assert_allclose(e, z["edge_e"], atol=1e-13)
+    np.testing.assert_allclose(A, z["edge_A"], atol=1e-13)
+    np.testing.assert_allclose(B, z["edge_B"], atol=1e-13)
+    H, b, err, idx = oracle.linearize(g, python_mode=True)
+    np.testing.assert_allclose(H, dense_from_coo(z), rtol=1e-12, atol=1e-9)
+    np.testing.assert_allclose(b, z["b"], rtol=1e-12, atol=1e-12)
+    assert abs(err - float(z["err"])) < 1e-12 * max(1.0, err)
+
+
+def test_huber_branch_is_exercised_by_fixtures():
+    # tiny_c's third landmark is far away: rho < chi2 there; C1 has 1623 of 2123 edges in the tail
+    z = load("c1_lin_f64.npz"); g = load("c1_graph.npz")
+    e = z["edge_e"]; w = g["e_inf"]
+    chi2 = (e * e * w).sum(1)
+    assert int((chi2 > 2.25).sum()) == 1623
+
+
+def test_vertex_update_fixture():
+    z = load("update_check.npz")
+    after = oracle.update_pose(z["pose_before"], z["delta"])
+    np.testing.assert_allclose(after, z["pose_after"], atol=1e-14)
+    assert abs(after[2]) <= np.pi                              # theta wraps through atan2
+
+
+def test_python_mode_trajectory_matches_reference_optimizer():
+    """GraphOptimizer.optimize(10, lr=.2) run by the reference itself vs the oracle's mode 1."""
+    z = load("c1_pyopt.npz")
+    g = oracle.Graph.from_npz(load("c1_graph.npz"), as_wire=True)
+    r = oracle.optimize(g, 10, mode="python", solver="chol", lr=0.2)
+    np.testing.assert_allclose(r["chi2"], z["chi2"], rtol=1e-9)
+    np.testing.assert_array_equal(g.v_id, z["v_id"])
+    d = r["v_pos"] - z["v_pos"]
+    d[:, 2] = (d[:, 2] + np.pi) % (2 * np.pi) - np.pi
+    assert np.abs(d).max() < 1e-8
+
+
+def test_qr_and_cholesky_agree_and_solve():
+    g = oracle.Graph.from_npz(load("c1_graph.npz"), as_wire=True)
+    H, b, err, _ = oracle.linearize(g)
+    x_qr = oracle.solve(H, b, "qr")
+    x_ch = oracle.solve(H, b, "chol")
+    x_np = np.linalg.solve(H, b)
+    s = np.abs(x_np).max()
+    assert np.abs(x_qr - x_np).max() < 1e-8 * s
+    assert np.abs(x_ch - x_np).max() < 1e-8 * s
+    assert np.abs(H @ x_qr - b).max() < 1e-7 * np.abs(b).max()
+
+
+def test_qr_rank_deficient_sets_free_unknowns_to_zero():
+    # an isolated landmark gives a zero row/column; Eigen's rank rule zeroes that unknown
+    H = np.diag([2.0, 3.0, 0.0, 0.0, 5.0]); H[0, 1] = H[1, 0] = 0.5
+    b = np.array([1.0, 2.0, 0.0, 0.0, 3.0])
+    x = oracle.solve(H, b, "qr")
+    assert x[2] == 0 and x[3] == 0
+    np.testing.assert_allclose(H @ x, b, atol=1e-14)
+
+
+def test_cpp_mode_trajectory_properties():
+    """The `cpu eigen` rules on C1: chi^2 decreases, plateau stop at iteration 40."""
+    g = oracle.Graph.from_npz(load("c1_graph.npz"), as_wire=True)
+    r = oracle.optimize(g, 50, mode="cpp", solver="chol")
+    chi = r["chi2"]
+    assert r["stop"] == "plateau"
+    assert 38 <= r["iters"] <= 43
+    assert np.all(np.diff(chi)[:-1] < 0) and abs(np.diff(chi)[-1]) < 1e-3   # last step is the plateau
+    assert abs(chi[0] - 114586.14856928238) < 1e-6
+    assert abs(chi[-1] - 624.14) < 0.5
+    # f32 (the reference server's scalar type, main.cpp:40) follows the same path loosely
+    r32 = oracle.optimize(g, 10, mode="cpp", solver="chol", precision="f32")
+    np.testing.assert_allclose(r32["chi2"], chi[:10], rtol=5e-3)

@@ -1,0 +1,168 @@
+/* tsgo.h — C ABI of the MI355X-native pose-graph optimizer (libtsgo_hip.so / libtsgo_host.so).
+ *
+ * This is the drop-in boundary for ToySlam's remote `graph_optimizer` hot path.  The reference has
+ * no FFI of its own: its optimizer sits behind the in-process C++ interfaces cited per entry point
+ * below (paths relative to the ToySlam tree), fed by the TCP codec.  Every entry point takes plain
+ * pointers and sizes, returns an int status (0 = ok, <0 = error, text via tsgo_last_error()), and
+ * never throws across the boundary.
+ *
+ * libtsgo_hip.so  : everything here (device entry points need a gfx950 GPU; they fail loudly
+ *                   without one — there is no CPU fallback).
+ * libtsgo_host.so : the host-only entry points (codec, synthetic graphs, problem layout), so that
+ *                   CPU-only tests can exercise the boundary logic.
+ */
+#ifndef TSGO_H
+#define TSGO_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- the OptGraph as plain arrays ----------------------------------------------------------------
+ * Mirrors the reference graph model: remote/graph/GraphCpu.h:12-59 (AddVertex/AddEdge/FixVertex),
+ * vertex/VertexType.h:3-7 (Se2 = 0, Point2 = 1), edge/EdgeType.h:3-7 (Se2 = 0 "ODOM", Se2Point2 = 1
+ * "LM"), python twin python/optimizer/opt_graph.py:7-18.
+ *   v_pos  : 3 doubles per vertex: (x, y, theta) for Se2, (x, y, 0) for Point2
+ *   e_meas : 9 doubles per edge: ODOM = the 3x3 measurement row-major (EdgeSe2.h); LM = (range,
+ *            bearing, 0...) (EdgeSe2Point2d.h:34-35)
+ *   e_inf  : 3 doubles per edge: the diagonal of the information matrix (the wire format carries
+ *            nothing else, DeserializeGraph.h:123-147); LM uses the first two
+ *   fixed  : vertex ids given to FixVertex; a repeated id adds the gauge term once per occurrence
+ *            (OptimizerCpu.h:132-138 iterates the vector) */
+typedef struct tsgo_graph {
+    int32_t n_vertices;
+    const uint32_t* v_id;
+    const uint32_t* v_type;
+    const double* v_pos;
+    int32_t n_edges;
+    const uint32_t* e_type;
+    const uint32_t* e_ids;   /* 2 per edge: id1, id2 */
+    const double* e_meas;
+    const double* e_inf;
+    int32_t n_fixed;
+    const uint32_t* fixed;
+} tsgo_graph;
+
+/* ---- optimizer -----------------------------------------------------------------------------------*/
+typedef struct tsgo_optimizer tsgo_optimizer;
+
+typedef struct tsgo_config {
+    int32_t device;          /* HIP device ordinal */
+    int32_t precision;       /* 64 (default, parity mode) or 32 */
+    double pcg_rel_tol;      /* stop PCG when sqrt(r^T M^-1 r) <= tol * sqrt(b^T M^-1 b); default 1e-10 */
+    int32_t pcg_max_iters;   /* cap per Gauss-Newton iteration; default 20000 */
+    int32_t lanes_per_pose;  /* 0 = auto; 1, 2, 4 or 8 lanes cooperate on one pose row */
+    int32_t lanes_per_lm;    /* 0 = auto */
+    int32_t use_graphs;      /* 1 (default): replay the PCG iteration from a hipGraph */
+    int32_t rank, world;     /* edge sharding: this process owns shard `rank` of `world` (default 0, 1) */
+    int32_t verbose;
+} tsgo_config;
+
+enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_CONVERGED = 3, TSGO_STOP_SOLVER = 4 };
+
+#define TSGO_MAX_TRACE 256
+typedef struct tsgo_stats {
+    int32_t iterations_run;              /* Gauss-Newton linearisations performed */
+    int32_t stop_reason;                 /* TSGO_STOP_*; rules of OptimizerCpu.h:140-153,167-177 */
+    double chi2[TSGO_MAX_TRACE];         /* robustified chi^2 at each linearisation (`err`, :117) */
+    int32_t pcg_iters[TSGO_MAX_TRACE];   /* PCG iterations of each solve */
+    double last_delta_norm;              /* ||delta||_2 of the last solve (unscaled, :173) */
+    double ms_total, ms_linearize, ms_solve, ms_update;   /* device time, hipEvent */
+    double ms_setup;                     /* host layout build + upload in tsgo_set_graph */
+    int64_t n_pose, n_lm, n_odom_edges, n_lm_edges;
+    int64_t pcg_iters_total;
+} tsgo_stats;
+
+/* Fills cfg with defaults. */
+void tsgo_default_config(tsgo_config* cfg);
+
+/* Replaces CreateOptimizer/CreateSolver/CreateGraph (remote/app/GraphManager.h:73-122): one handle
+ * holds the device buffers and is reusable across requests. */
+int tsgo_create(const tsgo_config* cfg, tsgo_optimizer** out);
+void tsgo_destroy(tsgo_optimizer* opt);
+
+/* Replaces the graph-builder policy Functions::CreateVertex/CreateEdge + graph->AddVertex/AddEdge/
+ * FixVertex (remote/serialization/DeserializeGraphFuncCpu.h:14-38, DeserializeGraph.h:43,52,151,172)
+ * and GraphGpu::ToDevice (remote/cuda/graph/GraphGpu.h:80-187).  Pointers are borrowed for the call. */
+int tsgo_set_graph(tsgo_optimizer* opt, const tsgo_graph* g);
+
+/* Replaces IOptimizer<T>::Optimize(IGraph*) (remote/optimizer/IOptimizer.h:21; loop semantics of
+ * OptimizerCpu.h:25-183) including ISolver<T>::Solve (remote/solver/ISolver.h:10).  The graph held by
+ * the handle is updated in place. */
+int tsgo_optimize(tsgo_optimizer* opt, int32_t iterations, tsgo_stats* stats);
+
+/* Replaces GraphGpu::ToHost (remote/cuda/graph/GraphGpu.h:190-224) / the vertex read-out of
+ * SerializeGraphFuncCpu::SerializeVertex (remote/serialization/SerializeGraphFuncCpu.h:10-41):
+ * v_pos_out has 3 doubles per vertex in the order of tsgo_graph.v_id; theta = atan2(R10, R00). */
+int tsgo_get_vertices(tsgo_optimizer* opt, double* v_pos_out);
+
+/* Parity probes (no reference counterpart; they expose what OptimizerCpu.h:82-138 builds).
+ * tsgo_linearize runs one linearisation at the current state and returns, per vertex in tsgo_graph
+ * order: diag (9 doubles, the dense diagonal block of H incl. the gauge term, row-major, 2x2 blocks
+ * use the leading 2x2) and grad (3 doubles, b = -J^T Omega_w e), plus chi2.
+ * tsgo_solve_step additionally solves H delta = b and returns delta (3 doubles per vertex, unscaled)
+ * without updating the vertices. */
+int tsgo_linearize(tsgo_optimizer* opt, double* diag_out, double* grad_out, double* chi2_out);
+int tsgo_solve_step(tsgo_optimizer* opt, double* delta_out, double* chi2_out, int32_t* pcg_iters_out);
+
+/* Multi-GPU (one process per GPU).  Rank 0 calls tsgo_comm_unique_id and ships the 128 bytes to the
+ * other ranks (any transport); every rank then calls tsgo_comm_init.  Collectives are RCCL. */
+int tsgo_comm_unique_id(uint8_t id_out[128]);
+int tsgo_comm_init(tsgo_optimizer* opt, const uint8_t id[128]);
+
+/* Timing probe used by bench.py: average device time (hipEvent, microseconds) of `reps` back-to-back
+ * launches of one kernel on the handle's stream, and the algorithmic bytes one launch moves.
+ * which: 0 schur_lm, 1 schur_pose, 2 cg_update, 3 lin_lm, 4 lin_pose, 5 one whole PCG iteration. */
+int tsgo_time_kernel(tsgo_optimizer* opt, int32_t which, int32_t reps, double* us_per_launch, double* bytes_per_launch);
+
+const char* tsgo_last_error(void);
+
+/* ---- host-only: wire codec (libtsgo_host.so and libtsgo_hip.so) ---------------------------------
+ * Request payload = what python/remote/graph_to_bytes.py:32-67 writes and
+ * remote/serialization/DeserializeGraph.h:18-173 reads (WITHOUT the 4-byte length prefix).
+ * Response = what remote/serialization/SerializeGraph.h:17-71 + SerializeGraphFuncCpu.h:10-65 write
+ * (WITH the u32 length prefix) and python/remote/bytes_to_graph.py:49-108 reads. */
+typedef struct tsgo_wire_graph tsgo_wire_graph;
+int tsgo_wire_decode(const uint8_t* payload, size_t len, tsgo_wire_graph** out);
+void tsgo_wire_view(const tsgo_wire_graph* w, tsgo_graph* view);
+/* Encodes the reply for the decoded request with vertex positions replaced by v_pos (3 doubles per
+ * vertex, request order).  Two-call pattern: buf = NULL returns the size. */
+int64_t tsgo_wire_encode_response(const tsgo_wire_graph* w, const double* v_pos, uint8_t* buf, size_t cap);
+/* Encodes a REQUEST (client side; byte-identical to graph_to_bytes for the same OptGraph), prefix
+ * included.  Two-call pattern. */
+int64_t tsgo_wire_encode_request(const tsgo_graph* g, uint8_t* buf, size_t cap);
+void tsgo_wire_free(tsgo_wire_graph* w);
+
+/* ---- host-only: synthetic graphs (BASELINE.json configs 2-5; definition in DESIGN.md) ------------*/
+typedef struct tsgo_synth_config {
+    int64_t n_poses;
+    int32_t lm_per_pose;        /* LM edges per pose (k nearest landmarks in range) */
+    double lm_obs_target;       /* aimed observations per landmark (sets landmark density) */
+    int32_t loop_closures;      /* extra ODOM edges between revisiting poses (config 5) */
+    uint64_t seed;
+} tsgo_synth_config;
+typedef struct tsgo_synth tsgo_synth;
+int tsgo_synth_create(const tsgo_synth_config* cfg, tsgo_synth** out);
+void tsgo_synth_view(const tsgo_synth* s, tsgo_graph* view);
+/* ground-truth vertex positions (3 doubles per vertex), for convergence checks */
+const double* tsgo_synth_truth(const tsgo_synth* s);
+void tsgo_synth_free(tsgo_synth* s);
+
+/* ---- host-only: layout probe (tests of the SELL builder and of the shard planner) ---------------*/
+typedef struct tsgo_layout_info {
+    int64_t n_pose, n_lm_local, n_lm_total, n_lm_edges_local, n_odom_slots;
+    int64_t rows_by_pose, rows_by_lm, rows_odom;      /* 64-lane rows incl. padding */
+    int32_t lanes_per_pose, lanes_per_lm;
+    int64_t lm_first, lm_last;                        /* landmark range owned (in landmark order of the graph) */
+    int64_t pose_first, pose_last;                    /* pose range whose ODOM rows/gauge this shard owns */
+} tsgo_layout_info;
+int tsgo_layout_probe(const tsgo_graph* g, int32_t rank, int32_t world, int32_t lanes_per_pose,
+                      int32_t lanes_per_lm, tsgo_layout_info* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TSGO_H */

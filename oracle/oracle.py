@@ -15,6 +15,7 @@ _LIB = None
 u32p = np.ctypeslib.ndpointer(np.uint32, flags="C_CONTIGUOUS")
 f64p = np.ctypeslib.ndpointer(np.float64, flags="C_CONTIGUOUS")
 i32p = np.ctypeslib.ndpointer(np.int32, flags="C_CONTIGUOUS")
+ALLREDUCE_FN = C.CFUNCTYPE(None, C.POINTER(C.c_double), C.c_int64, C.c_void_p)
 _GRAPH = [C.c_int, u32p, u32p, f64p, C.c_int, u32p, u32p, f64p, f64p, C.c_int, u32p]
 
 
@@ -37,10 +38,11 @@ def lib():
         L.oracle_solve_f64.argtypes = [f64p, f64p, C.c_int, C.c_int]
         L.oracle_update_pose_f64.argtypes = [f64p, f64p]
         L.oracle_num_unknowns.argtypes = [C.c_int, u32p]
-        if hasattr(L, "oracle_sparse_optimize"):
-            L.oracle_sparse_optimize.argtypes = _GRAPH + [f64p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
-                                                          f64p, i32p, i32p, i32p, f64p]
-            L.oracle_sparse_step.argtypes = _GRAPH + [C.c_double, C.c_int, C.c_int, f64p, f64p, i32p]
+        L.oracle_sparse_step.argtypes = _GRAPH + [C.c_double, C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p,
+                                                  f64p, f64p, i32p]
+        L.oracle_sparse_optimize.argtypes = _GRAPH + [f64p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+                                                      ALLREDUCE_FN, C.c_void_p, f64p, i32p, i32p, i32p, f64p,
+                                                      f64p, f64p]
         _LIB = L
     return _LIB
 
@@ -135,3 +137,37 @@ def update_pose(xyt, d):
     x = np.ascontiguousarray(xyt, np.float64).copy()
     lib().oracle_update_pose_f64(x, np.ascontiguousarray(d, np.float64))
     return x
+
+
+def _hook(allreduce):
+    """Wrap a python callable(np.ndarray) -> None (in-place sum over shards) as the C hook."""
+    if allreduce is None:
+        return C.cast(None, ALLREDUCE_FN)
+
+    def cb(ptr, n, _ctx):
+        allreduce(np.ctypeslib.as_array(ptr, shape=(n,)))
+    return ALLREDUCE_FN(cb)
+
+
+def sparse_step(g, pcg_tol=1e-12, max_cg=100000, rank=0, world=1, allreduce=None):
+    """One GN step by the sparse CPU twin (implicit-Schur PCG): dict(delta, chi2, cg_iters)."""
+    d = np.zeros((len(g.v_id), 3)); chi = np.zeros(1); it = np.zeros(1, np.int32)
+    h = _hook(allreduce)
+    rc = lib().oracle_sparse_step(*g.args(), pcg_tol, max_cg, rank, world, h, None, d, chi, it)
+    if rc:
+        raise RuntimeError("oracle_sparse_step rc=%d" % rc)
+    return dict(delta=d, chi2=float(chi[0]), cg_iters=int(it[0]))
+
+
+def sparse_optimize(g, iterations, pcg_tol=1e-12, max_cg=100000, rank=0, world=1, allreduce=None):
+    """Full GN loop by the sparse CPU twin with the reference's stop rules."""
+    out = np.zeros_like(g.v_pos); chi2 = np.zeros(max(iterations, 1)); cg = np.zeros(max(iterations, 1), np.int32)
+    ir = np.zeros(1, np.int32); sr = np.zeros(1, np.int32); dn = np.zeros(1); tl = np.zeros(1); ts = np.zeros(1)
+    h = _hook(allreduce)
+    rc = lib().oracle_sparse_optimize(*g.args(), out, iterations, pcg_tol, max_cg, rank, world, h, None, chi2, ir, sr,
+                                      cg, dn, tl, ts)
+    if rc:
+        raise RuntimeError("oracle_sparse_optimize rc=%d" % rc)
+    n = int(ir[0])
+    return dict(v_pos=out, chi2=chi2[:n].copy(), iters=n, stop=STOP[int(sr[0])], delta_norm=float(dn[0]),
+                cg_iters=cg[:n].copy(), seconds_linearize=float(tl[0]), seconds_solve=float(ts[0]))

@@ -1,0 +1,381 @@
+// oracle_sparse.cpp — TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// Scalar CPU twin of the sparse Gauss-Newton path the HIP library runs (same layout, same implicit
+// Schur-complement PCG, same stop rules), used
+//   * by tests/ as the checker at sizes where the dense restatement (oracle_dense.cpp) cannot run:
+//     it is itself validated against the dense restatement on the golden config-1 graph and on small
+//     synthetic graphs (tests/test_sparse_twin.py), and the HIP path is then compared with it;
+//   * by the world_size-2 gloo tests: every place the HIP path calls an RCCL all-reduce, this twin
+//     calls a user hook, so the sharded algorithm can run across CPU processes;
+//   * by bench.py as the `cpu_baseline` ("port": same math, NOT the reference's dense algorithm, which
+//     needs O(n^2) memory and cannot run configs 2-5: SURVEY.md section 0, finding 1).
+// It reuses the product's layout builder (toyslam_amd/csrc/host/problem.cpp) and per-edge arithmetic
+// (toyslam_amd/csrc/tsgo_math.h); nothing in the product links this file.
+//
+// GN loop rules: remote/optimizer/OptimizerCpu.h:80-180.  Per-edge math: tsgo_math.h (which cites
+// EdgeSe2Point2d.h / EdgeSe2.h).  Vertex update: VertexSe2.h:16-27, Vertex2d.h:16-19.
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "host/problem.h"
+#include "tsgo_math.h"
+
+namespace {
+
+using tsgo::kNoEdge; using tsgo::kWave; using tsgo::kDirBit;
+typedef void (*allreduce_fn)(double* buf, int64_t n, void* ctx);
+
+struct Twin {
+    tsgo::Problem pr;
+    allreduce_fn hook = nullptr; void* hook_ctx = nullptr;
+    int P = 0, L = 0;
+    std::vector<double> ps, th, ls;                 // pose (x,y,c,s), theta, landmark (x,y)
+    std::vector<double> pa, la;                     // 4 planes each: a0, a1, ppx, ppy (pose-major / lm-major)
+    std::vector<double> oa;                         // 3 planes (odom)
+    std::vector<double> dlinv, u, t;                // per landmark: 3, 2, 2
+    std::vector<double> part;                       // per pose 18: Dp(6) g(3) Sd(6) Wu(3); + 1 chi2 at the end
+    std::vector<double> dp, minv, r, z, p, q, x, s; // per pose
+    double chi2 = 0;
+
+    void allreduce(double* b, int64_t n) { if (hook && pr.world > 1) hook(b, n, hook_ctx); }
+
+    std::string init(const tsgo_graph& g, int rank, int world) {
+        tsgo::BuildOptions bo; bo.rank = rank; bo.world = world; bo.lanes_per_pose = 1; bo.lanes_per_lm = 1;
+        std::string e = tsgo::build_problem(g, bo, pr);
+        if (!e.empty()) return e;
+        P = pr.P; L = pr.L;
+        ps.resize((size_t)P * 4); th.resize(P); ls = pr.lm_xy;
+        for (int i = 0; i < P; ++i) {
+            th[i] = pr.pose_xyt[3 * (size_t)i + 2];
+            ps[4 * (size_t)i] = pr.pose_xyt[3 * (size_t)i]; ps[4 * (size_t)i + 1] = pr.pose_xyt[3 * (size_t)i + 1];
+            ps[4 * (size_t)i + 2] = std::cos(th[i]); ps[4 * (size_t)i + 3] = std::sin(th[i]);
+        }
+        pa.assign(4 * pr.by_pose.slots(), 0); la.assign(4 * pr.by_lm.slots(), 0); oa.assign(3 * pr.odom.slots(), 0);
+        dlinv.assign((size_t)L * 3, 0); u.assign((size_t)L * 2, 0); t.assign((size_t)L * 2, 0);
+        part.assign((size_t)P * 18 + 1, 0);
+        dp.assign((size_t)P * 6, 0); minv.assign((size_t)P * 6, 0);
+        for (auto* v : {&r, &z, &p, &q, &x, &s}) v->assign((size_t)P * 3, 0);
+        return std::string();
+    }
+
+    template <typename F> static void for_slots(const tsgo::SellTable& tb, int v, F f) {
+        const int vps = kWave / tb.G, sl = v / vps, base = (v % vps) * tb.G;
+        for (uint32_t row = tb.row_off[sl]; row < tb.row_off[sl + 1]; ++row)
+            for (int sub = 0; sub < tb.G; ++sub) {
+                const size_t slot = (size_t)row * kWave + base + sub;
+                if (tb.edge[slot] != kNoEdge) f(slot);
+            }
+    }
+
+    // K1: landmark side of the linearisation (B^T W B, B^T W e), block inverse, u = Dl^-1 g_l
+    void lin_lm() {
+        const tsgo::SellTable& tb = pr.by_lm; const size_t S = tb.slots();
+        #pragma omp parallel for schedule(static)
+        for (int l = 0; l < L; ++l) {
+            double dxx = pr.gauge_l[l], dxy = 0, dyy = pr.gauge_l[l], g0 = 0, g1 = 0;
+            const double lx = ls[2 * (size_t)l], ly = ls[2 * (size_t)l + 1];
+            for_slots(tb, l, [&](size_t k) {
+                const double* q4 = &ps[4 * (size_t)tb.idx[k]];
+                const double c = q4[2], sn = q4[3];
+                auto o = tsgo::lm_linearize<double>(q4[0], q4[1], c, sn, lx, ly, tb.plane(tsgo::LM_ZX)[k], tb.plane(tsgo::LM_ZY)[k],
+                                                   tb.plane(tsgo::LM_W0)[k], tb.plane(tsgo::LM_W1)[k]);
+                la[k] = o.a0; la[S + k] = o.a1; la[2 * S + k] = o.ppx; la[3 * S + k] = o.ppy;
+                dxx += o.a0 * c * c + o.a1 * sn * sn; dxy += (o.a0 - o.a1) * c * sn; dyy += o.a0 * sn * sn + o.a1 * c * c;
+                const double f0 = o.a0 * o.e0, f1 = o.a1 * o.e1;          // g_l = -B^T W e = -R (f0, f1)
+                g0 -= c * f0 - sn * f1; g1 -= sn * f0 + c * f1;
+            });
+            double ixx, ixy, iyy; tsgo::inv_sym2(dxx, dxy, dyy, ixx, ixy, iyy);
+            dlinv[3 * (size_t)l] = ixx; dlinv[3 * (size_t)l + 1] = ixy; dlinv[3 * (size_t)l + 2] = iyy;
+            u[2 * (size_t)l] = ixx * g0 + ixy * g1; u[2 * (size_t)l + 1] = ixy * g0 + iyy * g1;
+        }
+    }
+
+    // K2: pose side (A^T W A, A^T W e, Schur diagonal W Dl^-1 W^T, W u), ODOM rows, chi^2
+    void lin_pose() {
+        const tsgo::SellTable& tb = pr.by_pose; const size_t S = tb.slots();
+        const tsgo::SellTable& od = pr.odom; const size_t SO = od.slots();
+        double chi = 0;
+        #pragma omp parallel for schedule(static) reduction(+ : chi)
+        for (int i = 0; i < P; ++i) {
+            const double x0 = ps[4 * (size_t)i], y0 = ps[4 * (size_t)i + 1], c = ps[4 * (size_t)i + 2], sn = ps[4 * (size_t)i + 3];
+            double sA0 = 0, sA1 = 0, sAv0 = 0, sAv1 = 0, sVV = 0, ge0 = 0, ge1 = 0, get = 0;
+            double K00 = 0, K01 = 0, K11 = 0, Kv0 = 0, Kv1 = 0, vKv = 0, wu0 = 0, wu1 = 0, wut = 0;
+            for_slots(tb, i, [&](size_t k) {
+                const uint32_t l = tb.idx[k];
+                auto o = tsgo::lm_linearize<double>(x0, y0, c, sn, ls[2 * (size_t)l], ls[2 * (size_t)l + 1], tb.plane(tsgo::LM_ZX)[k],
+                                                   tb.plane(tsgo::LM_ZY)[k], tb.plane(tsgo::LM_W0)[k], tb.plane(tsgo::LM_W1)[k]);
+                pa[k] = o.a0; pa[S + k] = o.a1; pa[2 * S + k] = o.ppx; pa[3 * S + k] = o.ppy;
+                chi += o.rho;
+                const double v0 = o.ppy, v1 = -o.ppx;                      // A = [-R^T | v]
+                sA0 += o.a0; sA1 += o.a1; sAv0 += o.a0 * v0; sAv1 += o.a1 * v1; sVV += o.a0 * v0 * v0 + o.a1 * v1 * v1;
+                ge0 += o.a0 * o.e0; ge1 += o.a1 * o.e1; get += o.a0 * o.e0 * v0 + o.a1 * o.e1 * v1;
+                // N~ = R^T Dl^-1 R in the pose frame
+                const double nxx = dlinv[3 * (size_t)l], nxy = dlinv[3 * (size_t)l + 1], nyy = dlinv[3 * (size_t)l + 2];
+                const double n00 = c * c * nxx + 2 * c * sn * nxy + sn * sn * nyy;
+                const double n01 = c * sn * (nyy - nxx) + (c * c - sn * sn) * nxy;
+                const double n11 = sn * sn * nxx - 2 * c * sn * nxy + c * c * nyy;
+                const double k00 = o.a0 * n00 * o.a0, k01 = o.a0 * n01 * o.a1, k11 = o.a1 * n11 * o.a1;   // K = W~ N~ W~
+                K00 += k00; K01 += k01; K11 += k11;
+                const double kv0 = k00 * v0 + k01 * v1, kv1 = k01 * v0 + k11 * v1;
+                Kv0 += kv0; Kv1 += kv1; vKv += v0 * kv0 + v1 * kv1;
+                const double ux = u[2 * (size_t)l], uy = u[2 * (size_t)l + 1];
+                const double t0 = c * ux + sn * uy, t1 = c * uy - sn * ux;                               // tau = R^T u
+                wu0 += o.a0 * t0; wu1 += o.a1 * t1; wut += o.a0 * t0 * v0 + o.a1 * t1 * v1;
+            });
+            double* o18 = &part[(size_t)i * 18];
+            // rotate the pose-frame sums to the world frame
+            // Dp_tt = R diag(sA) R^T ; Dp_t,th = -R sAv ; Dp_th,th = sVV
+            o18[0] = c * c * sA0 + sn * sn * sA1; o18[1] = c * sn * (sA0 - sA1); o18[3] = sn * sn * sA0 + c * c * sA1;
+            o18[2] = -(c * sAv0 - sn * sAv1); o18[4] = -(sn * sAv0 + c * sAv1); o18[5] = sVV;
+            // g = -A^T W e = [R (ge0, ge1) ; -get]
+            o18[6] = c * ge0 - sn * ge1; o18[7] = sn * ge0 + c * ge1; o18[8] = -get;
+            // Sd = W Dl^-1 W^T = [[R K R^T, -R Kv], [., vKv]]
+            o18[9] = c * c * K00 - 2 * c * sn * K01 + sn * sn * K11;
+            o18[10] = c * sn * (K00 - K11) + (c * c - sn * sn) * K01;
+            o18[12] = sn * sn * K00 + 2 * c * sn * K01 + c * c * K11;
+            o18[11] = -(c * Kv0 - sn * Kv1); o18[13] = -(sn * Kv0 + c * Kv1); o18[14] = vKv;
+            // W u = [-R (wu0, wu1) ; wut]
+            o18[15] = -(c * wu0 - sn * wu1); o18[16] = -(sn * wu0 + c * wu1); o18[17] = wut;
+            // ODOM rows (both directions are listed; chi^2 counted at id1 only)
+            for_slots(od, i, [&](size_t k) {
+                const uint32_t raw = od.idx[k]; const bool second = raw & kDirBit; const uint32_t j = raw & ~kDirBit;
+                const double* me = &ps[4 * (size_t)i]; const double* ot = &ps[4 * (size_t)j];
+                const double* a = second ? ot : me; const double* b = second ? me : ot;
+                double mi[6], w[3];
+                for (int m = 0; m < 6; ++m) mi[m] = od.plane(tsgo::OD_MI0 + m)[k];
+                for (int m = 0; m < 3; ++m) w[m] = od.plane(tsgo::OD_W0 + m)[k];
+                auto o = tsgo::odom_linearize<double>(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], mi, w);
+                for (int m = 0; m < 3; ++m) oa[m * SO + k] = o.a[m];
+                o18[0] += o.a[0]; o18[3] += o.a[1]; o18[5] += o.a[2];
+                const double sg = second ? -1.0 : 1.0;                       // b1 += W e, b2 -= W e
+                for (int m = 0; m < 3; ++m) o18[6 + m] += sg * o.a[m] * o.e[m];
+                if (!second) chi += o.rho;
+            });
+        }
+        part[(size_t)P * 18] = chi;
+    }
+
+    // K3: M = Dp + gauge - Sd, M^-1, reduced rhs, CG start vectors.  Returns gamma0 = r^T M^-1 r.
+    double finalize() {
+        chi2 = part[(size_t)P * 18];
+        double gamma = 0;
+        #pragma omp parallel for schedule(static) reduction(+ : gamma)
+        for (int i = 0; i < P; ++i) {
+            const double* o18 = &part[(size_t)i * 18];
+            double m[6];
+            for (int k = 0; k < 6; ++k) { dp[6 * (size_t)i + k] = o18[k]; m[k] = o18[k] - o18[9 + k]; }
+            // NOTE: the gauge term of poses owned by other shards arrives through the all-reduce
+            tsgo::inv_sym3(m, &minv[6 * (size_t)i]);
+            for (int k = 0; k < 3; ++k) { r[3 * (size_t)i + k] = o18[6 + k] - o18[15 + k]; x[3 * (size_t)i + k] = 0; p[3 * (size_t)i + k] = 0; q[3 * (size_t)i + k] = 0; }
+            tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
+            for (int k = 0; k < 3; ++k) gamma += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
+        }
+        return gamma;
+    }
+
+    // KA: t = Dl^-1 W^T v   (v per pose, 3)
+    void schur_lm(const std::vector<double>& v) {
+        const tsgo::SellTable& tb = pr.by_lm; const size_t S = tb.slots();
+        #pragma omp parallel for schedule(static)
+        for (int l = 0; l < L; ++l) {
+            double a0s = 0, a1s = 0;
+            for_slots(tb, l, [&](size_t k) {
+                const uint32_t i = tb.idx[k];
+                const double c = ps[4 * (size_t)i + 2], sn = ps[4 * (size_t)i + 3];
+                const double v0 = v[3 * (size_t)i], v1 = v[3 * (size_t)i + 1], v2 = v[3 * (size_t)i + 2];
+                const double vt0 = c * v0 + sn * v1, vt1 = c * v1 - sn * v0;
+                const double m0 = la[k] * (-vt0 + la[3 * S + k] * v2), m1 = la[S + k] * (-vt1 - la[2 * S + k] * v2);
+                a0s += c * m0 - sn * m1; a1s += sn * m0 + c * m1;              // R m
+            });
+            const double* n = &dlinv[3 * (size_t)l];
+            t[2 * (size_t)l] = n[0] * a0s + n[1] * a1s; t[2 * (size_t)l + 1] = n[1] * a0s + n[2] * a1s;
+        }
+    }
+
+    // KB: out = Hpp v - W t  (partial over this shard's edges); returns partial dot (out, v)
+    double schur_pose(const std::vector<double>& v, std::vector<double>& out) {
+        const tsgo::SellTable& tb = pr.by_pose; const size_t S = tb.slots();
+        const tsgo::SellTable& od = pr.odom; const size_t SO = od.slots();
+        double dot = 0;
+        #pragma omp parallel for schedule(static) reduction(+ : dot)
+        for (int i = 0; i < P; ++i) {
+            const double c = ps[4 * (size_t)i + 2], sn = ps[4 * (size_t)i + 3];
+            double acc0 = 0, acc1 = 0, acc2 = 0;
+            for_slots(tb, i, [&](size_t k) {
+                const uint32_t l = tb.idx[k];
+                const double tx = t[2 * (size_t)l], ty = t[2 * (size_t)l + 1];
+                const double t0 = pa[k] * (c * tx + sn * ty), t1 = pa[S + k] * (c * ty - sn * tx);
+                acc0 += t0; acc1 += t1; acc2 += t0 * pa[3 * S + k] - t1 * pa[2 * S + k];
+            });
+            // -W t = [R (acc0, acc1) ; -acc2]
+            double o0 = c * acc0 - sn * acc1, o1 = sn * acc0 + c * acc1, o2 = -acc2;
+            const bool own = i >= pr.pose_first && i < pr.pose_last;
+            const double v0 = v[3 * (size_t)i], v1 = v[3 * (size_t)i + 1], v2 = v[3 * (size_t)i + 2];
+            if (own) {
+                // this shard's share of the diagonal block: LM part of every shard is in dp (all-reduced),
+                // so the FULL diagonal block is applied by the owner of the pose only
+                double d0, d1, d2; tsgo::sym3_mul(&dp[6 * (size_t)i], v0, v1, v2, d0, d1, d2);
+                o0 += d0; o1 += d1; o2 += d2;
+                for_slots(od, i, [&](size_t k) {
+                    const uint32_t j = od.idx[k] & ~kDirBit;
+                    o0 -= oa[k] * v[3 * (size_t)j]; o1 -= oa[SO + k] * v[3 * (size_t)j + 1]; o2 -= oa[2 * SO + k] * v[3 * (size_t)j + 2];
+                });
+            }
+            out[3 * (size_t)i] = o0; out[3 * (size_t)i + 1] = o1; out[3 * (size_t)i + 2] = o2;
+            dot += o0 * v0 + o1 * v1 + o2 * v2;
+        }
+        return dot;
+    }
+
+    // one linearisation: fills everything CG needs; returns gamma0
+    double linearize() {
+        lin_lm(); lin_pose();
+        // gauge of owned poses goes into the partial so that it is summed exactly once across shards
+        for (int i = pr.pose_first; i < pr.pose_last; ++i) { part[(size_t)i * 18] += pr.gauge_p[i]; part[(size_t)i * 18 + 3] += pr.gauge_p[i]; part[(size_t)i * 18 + 5] += pr.gauge_p[i]; }
+        allreduce(part.data(), (int64_t)part.size());
+        return finalize();
+    }
+
+    // Chronopoulos-Gear PCG on the reduced (pose) system S x = b~.  Returns iterations.
+    int solve(double gamma0, double tol, int max_it, bool* ok) {
+        std::vector<double> buf((size_t)P * 3 + 1);
+        double gamma = gamma0, gamma_old = 0, alpha_old = 0;
+        *ok = true;
+        if (!(gamma0 > 0)) return 0;
+        int it = 0;
+        for (; it < max_it; ++it) {
+            if (gamma <= tol * tol * gamma0) break;
+            schur_lm(z);
+            buf[(size_t)P * 3] = schur_pose(z, buf);
+            allreduce(buf.data(), (int64_t)buf.size());
+            const double delta = buf[(size_t)P * 3];
+            double alpha, beta;
+            if (it == 0) { beta = 0; alpha = gamma / delta; }
+            else { beta = gamma / gamma_old; alpha = gamma / (delta - beta * gamma / alpha_old); }
+            if (!(alpha > 0) || !std::isfinite(alpha)) { *ok = false; break; }
+            double gnew = 0;
+            #pragma omp parallel for schedule(static) reduction(+ : gnew)
+            for (int i = 0; i < P; ++i) {
+                for (int k = 0; k < 3; ++k) {
+                    const size_t j = 3 * (size_t)i + k;
+                    p[j] = z[j] + beta * p[j]; q[j] = buf[j] + beta * q[j];
+                    x[j] += alpha * p[j]; r[j] -= alpha * q[j];
+                }
+                tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
+                for (int k = 0; k < 3; ++k) gnew += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
+            }
+            gamma_old = gamma; alpha_old = alpha; gamma = gnew;
+        }
+        return it;
+    }
+
+    // back-substitution for the landmarks: delta_l = u - Dl^-1 W^T delta_p
+    void backsub(std::vector<double>& dl) {
+        schur_lm(x);
+        dl.resize((size_t)L * 2);
+        for (size_t k = 0; k < dl.size(); ++k) dl[k] = u[k] - t[k];
+    }
+
+    // VertexSe2.h:16-27, Vertex2d.h:16-19 with the 0.2 step of OptimizerCpu.h:164
+    double update(const std::vector<double>& dl) {
+        double n2 = 0;
+        for (int i = 0; i < P; ++i) {
+            const double* d = &x[3 * (size_t)i];
+            n2 += d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
+            ps[4 * (size_t)i] += tsgo::kStepScale * d[0]; ps[4 * (size_t)i + 1] += tsgo::kStepScale * d[1];
+            const double nt = std::atan2(ps[4 * (size_t)i + 3], ps[4 * (size_t)i + 2]) + tsgo::kStepScale * d[2];
+            th[i] = nt; ps[4 * (size_t)i + 2] = std::cos(nt); ps[4 * (size_t)i + 3] = std::sin(nt);
+        }
+        double l2 = 0;
+        for (int l = 0; l < L; ++l) {
+            l2 += dl[2 * (size_t)l] * dl[2 * (size_t)l] + dl[2 * (size_t)l + 1] * dl[2 * (size_t)l + 1];
+            ls[2 * (size_t)l] += tsgo::kStepScale * dl[2 * (size_t)l]; ls[2 * (size_t)l + 1] += tsgo::kStepScale * dl[2 * (size_t)l + 1];
+        }
+        // landmark deltas are shard-local: sum their squared norm across shards
+        double b[1] = {l2}; allreduce(b, 1);
+        return std::sqrt(n2 + b[0]);
+    }
+
+    void store(double* v_pos, double* delta_or_null, const std::vector<double>* dl) const {
+        for (int i = 0; i < P; ++i) {
+            const int v = pr.pose_vertex[i];
+            if (v_pos) { v_pos[3 * (size_t)v] = ps[4 * (size_t)i]; v_pos[3 * (size_t)v + 1] = ps[4 * (size_t)i + 1]; v_pos[3 * (size_t)v + 2] = std::atan2(ps[4 * (size_t)i + 3], ps[4 * (size_t)i + 2]); }
+            if (delta_or_null) for (int k = 0; k < 3; ++k) delta_or_null[3 * (size_t)v + k] = x[3 * (size_t)i + k];
+        }
+        for (int l = 0; l < L; ++l) {
+            const int v = pr.lm_vertex[l];
+            if (v_pos) { v_pos[3 * (size_t)v] = ls[2 * (size_t)l]; v_pos[3 * (size_t)v + 1] = ls[2 * (size_t)l + 1]; v_pos[3 * (size_t)v + 2] = 0; }
+            if (delta_or_null && dl) { delta_or_null[3 * (size_t)v] = (*dl)[2 * (size_t)l]; delta_or_null[3 * (size_t)v + 1] = (*dl)[2 * (size_t)l + 1]; delta_or_null[3 * (size_t)v + 2] = 0; }
+        }
+    }
+};
+
+tsgo_graph make_view(int nV, const uint32_t* v_id, const uint32_t* v_type, const double* v_pos, int nE, const uint32_t* e_type,
+                     const uint32_t* e_ids, const double* e_meas, const double* e_inf, int nF, const uint32_t* fixed) {
+    tsgo_graph g; g.n_vertices = nV; g.v_id = v_id; g.v_type = v_type; g.v_pos = v_pos; g.n_edges = nE; g.e_type = e_type;
+    g.e_ids = e_ids; g.e_meas = e_meas; g.e_inf = e_inf; g.n_fixed = nF; g.fixed = fixed; return g;
+}
+
+}  // namespace
+
+#define GRAPH_ARGS int nV, const uint32_t* v_id, const uint32_t* v_type, const double* v_pos, int nE, \
+    const uint32_t* e_type, const uint32_t* e_ids, const double* e_meas, const double* e_inf, int nF, const uint32_t* fixed
+#define GRAPH_PASS nV, v_id, v_type, v_pos, nE, e_type, e_ids, e_meas, e_inf, nF, fixed
+
+extern "C" {
+
+// One Gauss-Newton step at the given state: delta (3 per vertex, graph order; landmarks of other
+// shards are left 0), chi2, PCG iterations.  hook/ctx: all-reduce(sum) over shards, may be NULL.
+int oracle_sparse_step(GRAPH_ARGS, double pcg_tol, int max_cg, int rank, int world, allreduce_fn hook, void* ctx,
+                       double* delta_out, double* chi2_out, int* cg_iters) {
+    Twin tw; tw.hook = hook; tw.hook_ctx = ctx;
+    const tsgo_graph g = make_view(GRAPH_PASS);
+    if (!tw.init(g, rank, world).empty()) return -2;
+    const double gamma0 = tw.linearize();
+    bool ok; *cg_iters = tw.solve(gamma0, pcg_tol, max_cg, &ok);
+    std::vector<double> dl; tw.backsub(dl);
+    std::memset(delta_out, 0, sizeof(double) * 3 * (size_t)nV);
+    tw.store(nullptr, delta_out, &dl);
+    *chi2_out = tw.chi2;
+    return ok ? 0 : -4;
+}
+
+// Full loop with the reference's rules (OptimizerCpu.h:80-180).  v_pos_out: 3 per vertex (landmarks of
+// other shards are left at their input value).  stop_reason as in oracle_dense.cpp.
+int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double pcg_tol, int max_cg, int rank, int world,
+                           allreduce_fn hook, void* ctx, double* chi2_trace, int* iters_run, int* stop_reason,
+                           int* cg_trace, double* last_delta_norm, double* seconds_lin, double* seconds_solve) {
+    Twin tw; tw.hook = hook; tw.hook_ctx = ctx;
+    const tsgo_graph g = make_view(GRAPH_PASS);
+    if (!tw.init(g, rank, world).empty()) return -2;
+    std::memcpy(v_pos_out, v_pos, sizeof(double) * 3 * (size_t)nV);
+    double prevErr = -1; int penalty = 0;
+    *stop_reason = 0; *iters_run = 0; *last_delta_norm = 0;
+    if (seconds_lin) *seconds_lin = 0;
+    if (seconds_solve) *seconds_solve = 0;
+    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    for (int it = 0; it < iterations; ++it) {
+        double t0 = now();
+        const double gamma0 = tw.linearize();
+        double t1 = now(); if (seconds_lin) *seconds_lin += t1 - t0;
+        const double err = tw.chi2;
+        chi2_trace[it] = err; *iters_run = it + 1;
+        if (prevErr > 0 && err > prevErr) { if (++penalty > 2) { *stop_reason = 1; break; } } else penalty = 0;
+        bool ok; cg_trace[it] = tw.solve(gamma0, pcg_tol, max_cg, &ok);
+        if (!ok) { *stop_reason = 4; break; }
+        std::vector<double> dl; tw.backsub(dl);
+        const double nrm = tw.update(dl);
+        if (seconds_solve) *seconds_solve += now() - t1;
+        *last_delta_norm = nrm;
+        if (std::fabs(err - prevErr) < tsgo::kPlateauTol) { *stop_reason = 2; break; }
+        if (nrm < tsgo::kDeltaTol) { *stop_reason = 3; break; }
+        prevErr = err;
+    }
+    tw.store(v_pos_out, nullptr, nullptr);
+    return 0;
+}
+
+}  // extern "C"

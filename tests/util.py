@@ -1,0 +1,57 @@
+"""Shared helpers for the tests (the oracle is imported HERE and in tests only)."""
+import os
+
+import numpy as np
+
+from oracle import oracle
+from toyslam_amd.graph import GraphArrays
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+def to_oracle(g):
+    return oracle.Graph(g.v_id, g.v_type, g.v_pos, g.e_type, g.e_ids, g.e_meas, g.e_inf, g.fixed)
+
+
+def to_arrays(g):
+    return GraphArrays(g.v_id, g.v_type, g.v_pos, g.e_type, g.e_ids, g.e_meas, g.e_inf, g.fixed)
+
+
+def c1_arrays(as_wire=True):
+    z = load("c1_graph.npz")
+    g = GraphArrays(z["v_id"], z["v_type"], z["v_pos"], z["e_type"], z["e_ids"], z["e_meas"], z["e_inf"], z["fixed"])
+    return g.rounded_to_wire() if as_wire else g
+
+
+def tiny_arrays(name):
+    z = load(name + ".npz")
+    return GraphArrays(z["v_id"], z["v_type"], z["v_pos"], z["e_type"], z["e_ids"], z["e_meas"], z["e_inf"], z["fixed"])
+
+
+def dense_solution(g):
+    """H delta = b by the dense oracle + LAPACK; returns per-vertex (n,3) delta, chi2, diag blocks, grad."""
+    o = to_oracle(g)
+    H, b, err, idx = oracle.linearize(o)
+    x = np.linalg.solve(H, b)
+    dims = np.where(o.v_type == 0, 3, 2)
+    d = np.zeros((len(o.v_id), 3)); gr = np.zeros((len(o.v_id), 3)); dg = np.zeros((len(o.v_id), 9))
+    for i in range(len(o.v_id)):
+        k, m = idx[i], dims[i]
+        d[i, :m] = x[k:k + m]; gr[i, :m] = b[k:k + m]
+        blk = np.zeros((3, 3)); blk[:m, :m] = H[k:k + m, k:k + m]
+        dg[i] = blk.reshape(-1)
+    return d, err, dg, gr
+
+
+def angle_diff(a, b):
+    return (a - b + np.pi) % (2 * np.pi) - np.pi
+
+
+def max_vertex_diff(v1, v2, v_type):
+    d = np.abs(v1 - v2)
+    d[:, 2] = np.where(v_type == 0, np.abs(angle_diff(v1[:, 2], v2[:, 2])), 0.0)
+    return float(d.max())

@@ -1,0 +1,64 @@
+"""In-tree builds: libtsgo_hip.so (hipcc, gfx950), libtsgo_host.so (g++), graph_optimizer (server)."""
+import os
+import shutil
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+HOST_SRC = ["host/problem.cpp", "host/codec.cpp", "host/synth.cpp", "host/host_api.cpp", "host/errors.cpp"]
+HIP_SO = os.path.join(HERE, "libtsgo_hip.so")
+HOST_SO = os.path.join(HERE, "libtsgo_host.so")
+SERVER = os.path.join(HERE, "graph_optimizer")
+
+
+def _newer(target, sources):
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(s) > t for s in sources)
+
+
+def _all_sources():
+    out = []
+    for root, _d, files in os.walk(CSRC):
+        out += [os.path.join(root, f) for f in files if f.endswith((".h", ".hip", ".cpp"))]
+    out.append(os.path.join(os.path.dirname(HERE), "include", "tsgo.h"))
+    return out
+
+
+def hipcc():
+    return shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+
+
+def build_host(force=False):
+    if force or _newer(HOST_SO, _all_sources()):
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared", "-o", HOST_SO] + HOST_SRC
+        subprocess.check_call(cmd, cwd=CSRC)
+    return HOST_SO
+
+
+def build_hip(force=False):
+    if force or _newer(HIP_SO, _all_sources()):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
+               "-o", HIP_SO, "tsgo_hip.hip"] + HOST_SRC + ["-lrccl"]
+        subprocess.check_call(cmd, cwd=CSRC)
+    return HIP_SO
+
+
+def build_server(force=False):
+    src = os.path.join(CSRC, "host", "server.cpp")
+    if not os.path.exists(src):
+        return None
+    if force or _newer(SERVER, _all_sources()):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-Wno-unused-result", "-o", SERVER,
+               "host/server.cpp", "tsgo_hip.hip"] + HOST_SRC + ["-lrccl", "-lpthread"]
+        subprocess.check_call(cmd, cwd=CSRC)
+    return SERVER
+
+
+def build_all(force=False):
+    return build_host(force), build_hip(force), build_server(force)
+
+
+if __name__ == "__main__":
+    print(build_all(force=True))

@@ -1,0 +1,26 @@
+// host_api.cpp — host-only C-ABI entry points that need no GPU (see include/tsgo.h).
+#include "../../../include/tsgo.h"
+#include "errors.h"
+#include "problem.h"
+
+extern "C" void tsgo_default_config(tsgo_config* c) {
+    if (!c) return;
+    c->device = 0; c->precision = 64; c->pcg_rel_tol = 1e-10; c->pcg_max_iters = 20000;
+    c->lanes_per_pose = 0; c->lanes_per_lm = 0; c->use_graphs = 1; c->rank = 0; c->world = 1; c->verbose = 0;
+}
+
+extern "C" int tsgo_layout_probe(const tsgo_graph* g, int32_t rank, int32_t world, int32_t lanes_per_pose,
+                                 int32_t lanes_per_lm, tsgo_layout_info* out) {
+    if (!g || !out) return tsgo::set_error(-1, "tsgo_layout_probe: null argument");
+    tsgo::Problem pr;
+    tsgo::BuildOptions bo; bo.rank = rank; bo.world = world; bo.lanes_per_pose = lanes_per_pose; bo.lanes_per_lm = lanes_per_lm;
+    const std::string err = tsgo::build_problem(*g, bo, pr);
+    if (!err.empty()) return tsgo::set_error(-2, err);
+    out->n_pose = pr.P; out->n_lm_local = pr.L; out->n_lm_total = pr.L_total; out->n_lm_edges_local = pr.n_lm_edges;
+    int64_t od = 0; for (uint32_t e : pr.odom.edge) od += e != tsgo::kNoEdge;
+    out->n_odom_slots = od;
+    out->rows_by_pose = (int64_t)pr.by_pose.rows; out->rows_by_lm = (int64_t)pr.by_lm.rows; out->rows_odom = (int64_t)pr.odom.rows;
+    out->lanes_per_pose = pr.by_pose.G; out->lanes_per_lm = pr.by_lm.G;
+    out->lm_first = pr.lm_first; out->lm_last = pr.lm_last; out->pose_first = pr.pose_first; out->pose_last = pr.pose_last;
+    return 0;
+}

@@ -1,0 +1,233 @@
+// problem.cpp — builds the device-ready layout (see problem.h) from a tsgo_graph.
+#include "problem.h"
+
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+#include <unordered_map>
+
+namespace tsgo {
+
+bool invert3(const double* m, double* out) {
+    double a[3][6];
+    for (int i = 0; i < 3; ++i)
+        for (int j = 0; j < 3; ++j) { a[i][j] = m[i * 3 + j]; a[i][3 + j] = (i == j) ? 1.0 : 0.0; }
+    for (int col = 0; col < 3; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 3; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (!(std::fabs(a[piv][col]) > 0.0)) return false;
+        if (piv != col) for (int j = 0; j < 6; ++j) std::swap(a[piv][j], a[col][j]);
+        const double d = a[col][col];
+        for (int j = 0; j < 6; ++j) a[col][j] /= d;
+        for (int r = 0; r < 3; ++r) if (r != col) {
+            const double f = a[r][col];
+            for (int j = 0; j < 6; ++j) a[r][j] -= f * a[col][j];
+        }
+    }
+    for (int i = 0; i < 3; ++i) for (int j = 0; j < 3; ++j) out[i * 3 + j] = a[i][3 + j];
+    return true;
+}
+
+namespace {
+
+int auto_lanes(double mean_degree) {
+    if (mean_degree >= 24) return 8;
+    if (mean_degree >= 12) return 4;
+    if (mean_degree >= 6) return 2;
+    return 1;
+}
+
+bool valid_lanes(int g) { return g == 1 || g == 2 || g == 4 || g == 8; }
+
+// order[i] = class index placed at internal position i; degree-descending inside windows.
+std::vector<int> window_sort(const std::vector<int>& degree) {
+    std::vector<int> order(degree.size());
+    std::iota(order.begin(), order.end(), 0);
+    for (size_t b = 0; b < order.size(); b += kSortWindow) {
+        const size_t e = std::min(order.size(), b + (size_t)kSortWindow);
+        std::stable_sort(order.begin() + b, order.begin() + e, [&](int x, int y) { return degree[x] > degree[y]; });
+    }
+    return order;
+}
+
+// Shapes a SELL table for per-vertex degrees (internal numbering) and returns, through `place`,
+// a function-like table: slot_of(v, k) = position of the k-th entry of vertex v.
+void shape_table(SellTable& t, int G, const std::vector<int>& degree, int n_planes) {
+    t.G = G; t.n_vertices = (int)degree.size(); t.n_planes = n_planes;
+    const int vps = kWave / G;
+    t.n_slices = (t.n_vertices + vps - 1) / vps;
+    t.row_off.assign(t.n_slices + 1, 0);
+    for (int s = 0; s < t.n_slices; ++s) {
+        int w = 0;
+        for (int v = s * vps; v < std::min(t.n_vertices, (s + 1) * vps); ++v) w = std::max(w, (degree[v] + G - 1) / G);
+        t.row_off[s + 1] = t.row_off[s] + (uint32_t)w;
+    }
+    t.rows = t.row_off[t.n_slices];
+    t.idx.assign(t.slots(), 0u);
+    t.edge.assign(t.slots(), kNoEdge);
+    t.planes.assign((size_t)n_planes * t.slots(), 0.0);
+}
+
+inline size_t slot_of(const SellTable& t, int v, int k) {
+    const int vps = kWave / t.G;
+    const int s = v / vps, lane = (v % vps) * t.G + (k % t.G);
+    return ((size_t)t.row_off[s] + (size_t)(k / t.G)) * kWave + (size_t)lane;
+}
+
+}  // namespace
+
+std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem& out) {
+    Problem pr;
+    pr.rank = opt.rank; pr.world = std::max(1, opt.world);
+    if (pr.rank < 0 || pr.rank >= pr.world) return "rank outside [0, world)";
+    if (g.n_vertices < 0 || g.n_edges < 0 || g.n_fixed < 0) return "negative count";
+    const int nV = g.n_vertices, nE = g.n_edges;
+    pr.n_vertices = nV;
+
+    // ---- classify vertices -----------------------------------------------------------------------
+    std::vector<int> cls(nV);                 // class index within its type
+    std::vector<int> pose_pos, lm_pos;        // class index -> vertex position
+    std::unordered_map<uint32_t, int> by_id;
+    by_id.reserve((size_t)nV * 2);
+    for (int i = 0; i < nV; ++i) {
+        const uint32_t t = g.v_type[i];
+        if (t == 0) { cls[i] = (int)pose_pos.size(); pose_pos.push_back(i); }
+        else if (t == 1) { cls[i] = (int)lm_pos.size(); lm_pos.push_back(i); }
+        else return "unknown vertex type " + std::to_string(t);
+        if (!by_id.emplace(g.v_id[i], i).second) return "duplicate vertex id " + std::to_string(g.v_id[i]);
+    }
+    const int P = (int)pose_pos.size(), Lt = (int)lm_pos.size();
+    pr.P = P; pr.L_total = Lt;
+
+    // ---- validate edges, degrees -------------------------------------------------------------------
+    std::vector<int> ev1(nE), ev2(nE);        // vertex positions of the endpoints
+    std::vector<int> deg_pose_lm(P, 0), deg_lm(Lt, 0), deg_pose_od(P, 0);
+    for (int e = 0; e < nE; ++e) {
+        auto a = by_id.find(g.e_ids[2 * (size_t)e]), b = by_id.find(g.e_ids[2 * (size_t)e + 1]);
+        if (a == by_id.end() || b == by_id.end())
+            return "edge " + std::to_string(e) + " refers to an unknown vertex id";
+        ev1[e] = a->second; ev2[e] = b->second;
+        const uint32_t t = g.e_type[e];
+        if (t == 0) {
+            if (g.v_type[ev1[e]] != 0 || g.v_type[ev2[e]] != 0) return "ODOM edge " + std::to_string(e) + " must join two Se2 vertices";
+            ++deg_pose_od[cls[ev1[e]]]; ++deg_pose_od[cls[ev2[e]]];
+            ++pr.n_odom_edges_total;
+        } else if (t == 1) {
+            if (g.v_type[ev1[e]] != 0 || g.v_type[ev2[e]] != 1) return "LM edge " + std::to_string(e) + " must join an Se2 vertex to a Point2 vertex";
+            ++deg_pose_lm[cls[ev1[e]]]; ++deg_lm[cls[ev2[e]]];
+            ++pr.n_lm_edges_total;
+        } else return "unknown edge type " + std::to_string(t);
+    }
+
+    // ---- shard: contiguous landmark range balanced by LM-edge count; contiguous pose range --------
+    {
+        const int64_t total = pr.n_lm_edges_total;
+        auto bound = [&](int r) -> int {         // first landmark class index of shard r
+            if (r <= 0) return 0;
+            if (r >= pr.world) return Lt;
+            const int64_t target = (total * r) / pr.world;
+            int64_t acc = 0; int j = 0;
+            while (j < Lt && acc + deg_lm[j] <= target) { acc += deg_lm[j]; ++j; }
+            // with no LM edges at all fall back to an even split of the landmarks
+            if (total == 0) j = (int)(((int64_t)Lt * r) / pr.world);
+            return j;
+        };
+        pr.lm_first = bound(pr.rank); pr.lm_last = bound(pr.rank + 1);
+        pr.pose_first = (int)(((int64_t)P * pr.rank) / pr.world);
+        pr.pose_last = (int)(((int64_t)P * (pr.rank + 1)) / pr.world);
+    }
+    const int L = pr.lm_last - pr.lm_first;
+    pr.L = L;
+
+    // ---- internal numbering --------------------------------------------------------------------------
+    // poses: global (identical on every shard) -> sort by the FULL graph's LM degree
+    const std::vector<int> pose_order = window_sort(deg_pose_lm);       // internal -> class
+    std::vector<int> pose_internal(P);
+    for (int i = 0; i < P; ++i) pose_internal[pose_order[i]] = i;
+    std::vector<int> deg_lm_local(deg_lm.begin() + pr.lm_first, deg_lm.begin() + pr.lm_last);
+    const std::vector<int> lm_order = window_sort(deg_lm_local);        // internal(local) -> class - lm_first
+    std::vector<int> lm_internal(L);
+    for (int i = 0; i < L; ++i) lm_internal[lm_order[i]] = i;
+
+    pr.pose_vertex.resize(P); pr.pose_xyt.resize((size_t)P * 3); pr.gauge_p.assign(P, 0.0);
+    for (int i = 0; i < P; ++i) {
+        const int v = pose_pos[pose_order[i]];
+        pr.pose_vertex[i] = v;
+        for (int k = 0; k < 3; ++k) pr.pose_xyt[(size_t)i * 3 + k] = g.v_pos[(size_t)v * 3 + k];
+    }
+    pr.lm_vertex.resize(L); pr.lm_xy.resize((size_t)L * 2); pr.gauge_l.assign(L, 0.0);
+    for (int i = 0; i < L; ++i) {
+        const int v = lm_pos[pr.lm_first + lm_order[i]];
+        pr.lm_vertex[i] = v;
+        pr.lm_xy[(size_t)i * 2] = g.v_pos[(size_t)v * 3]; pr.lm_xy[(size_t)i * 2 + 1] = g.v_pos[(size_t)v * 3 + 1];
+    }
+    for (int i = 0; i < g.n_fixed; ++i) {
+        auto it = by_id.find(g.fixed[i]);
+        if (it == by_id.end()) return "fixed vertex id " + std::to_string(g.fixed[i]) + " is unknown";
+        const int v = it->second;
+        if (g.v_type[v] == 0) {
+            const int p = pose_internal[cls[v]];
+            if (p >= pr.pose_first && p < pr.pose_last) pr.gauge_p[p] += kGaugeTerm;
+        } else {
+            const int c = cls[v];
+            if (c >= pr.lm_first && c < pr.lm_last) pr.gauge_l[lm_internal[c - pr.lm_first]] += kGaugeTerm;
+        }
+    }
+
+    // ---- per-vertex degrees in internal numbering (owned edges only) ---------------------------------
+    std::vector<int> dP(P, 0), dL(L, 0), dO(P, 0);
+    for (int e = 0; e < nE; ++e) {
+        if (g.e_type[e] == 1) {
+            const int c = cls[ev2[e]];
+            if (c < pr.lm_first || c >= pr.lm_last) continue;
+            ++dP[pose_internal[cls[ev1[e]]]]; ++dL[lm_internal[c - pr.lm_first]]; ++pr.n_lm_edges;
+        } else {
+            const int p1 = pose_internal[cls[ev1[e]]], p2 = pose_internal[cls[ev2[e]]];
+            if (p1 >= pr.pose_first && p1 < pr.pose_last) ++dO[p1];
+            if (p2 >= pr.pose_first && p2 < pr.pose_last) ++dO[p2];
+        }
+    }
+    int Gp = opt.lanes_per_pose, Gl = opt.lanes_per_lm;
+    if (Gp == 0) Gp = auto_lanes(P ? (double)pr.n_lm_edges / P : 0.0);
+    if (Gl == 0) Gl = auto_lanes(L ? (double)pr.n_lm_edges / L : 0.0);
+    if (!valid_lanes(Gp) || !valid_lanes(Gl)) return "lanes per vertex must be 1, 2, 4 or 8";
+
+    shape_table(pr.by_pose, Gp, dP, LM_PLANES);
+    shape_table(pr.by_lm, Gl, dL, LM_PLANES);
+    shape_table(pr.odom, Gp, dO, OD_PLANES);
+
+    // ---- fill ----------------------------------------------------------------------------------------
+    std::vector<int> fillP(P, 0), fillL(L, 0), fillO(P, 0);
+    for (int e = 0; e < nE; ++e) {
+        const double* m = g.e_meas + (size_t)e * 9;
+        const double* w = g.e_inf + (size_t)e * 3;
+        if (g.e_type[e] == 1) {
+            const int c = cls[ev2[e]];
+            if (c < pr.lm_first || c >= pr.lm_last) continue;
+            const int p = pose_internal[cls[ev1[e]]], l = lm_internal[c - pr.lm_first];
+            const double zx = m[0] * std::cos(m[1]), zy = m[0] * std::sin(m[1]);   // EdgeSe2Point2d.h:34-35
+            const size_t sp = slot_of(pr.by_pose, p, fillP[p]++), sl = slot_of(pr.by_lm, l, fillL[l]++);
+            pr.by_pose.idx[sp] = (uint32_t)l; pr.by_pose.edge[sp] = (uint32_t)e;
+            pr.by_lm.idx[sl] = (uint32_t)p; pr.by_lm.edge[sl] = (uint32_t)e;
+            const double vals[LM_PLANES] = {zx, zy, w[0], w[1]};
+            for (int k = 0; k < LM_PLANES; ++k) { pr.by_pose.plane(k)[sp] = vals[k]; pr.by_lm.plane(k)[sl] = vals[k]; }
+        } else {
+            double inv[9];
+            if (!invert3(m, inv)) return "ODOM edge " + std::to_string(e) + " has a singular measurement matrix";
+            const int p1 = pose_internal[cls[ev1[e]]], p2 = pose_internal[cls[ev2[e]]];
+            for (int side = 0; side < 2; ++side) {
+                const int self = side ? p2 : p1, other = side ? p1 : p2;
+                if (self < pr.pose_first || self >= pr.pose_last) continue;
+                const size_t so = slot_of(pr.odom, self, fillO[self]++);
+                pr.odom.idx[so] = (uint32_t)other | (side ? kDirBit : 0u);
+                pr.odom.edge[so] = (uint32_t)e;
+                for (int k = 0; k < 6; ++k) pr.odom.plane(OD_MI0 + k)[so] = inv[k];
+                for (int k = 0; k < 3; ++k) pr.odom.plane(OD_W0 + k)[so] = w[k];
+            }
+        }
+    }
+    out = std::move(pr);
+    return std::string();
+}
+
+}  // namespace tsgo

@@ -1,0 +1,532 @@
+// tsgo_hip.hip — device side of the C ABI in include/tsgo.h: buffers, launches, the Gauss-Newton
+// loop with the reference's stop rules (remote/optimizer/OptimizerCpu.h:80-180), hipGraph replay of
+// the PCG iteration, RCCL all-reduces for edge-sharded runs.  Kernels: tsgo_kernels.h.
+//
+// There is NO CPU fallback in this file: every entry point that computes needs a gfx950 device and
+// returns an error otherwise.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/tsgo.h"
+#include "host/errors.h"
+#include "host/problem.h"
+#include "tsgo_kernels.h"
+
+namespace {
+
+using namespace tsgo;
+
+#define HIP_OK(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return set_error(-10, std::string(#expr) + ": " + hipGetErrorString(e_));                  \
+    } while (0)
+#define NCCL_OK(expr)                                                                                  \
+    do {                                                                                               \
+        ncclResult_t e_ = (expr);                                                                      \
+        if (e_ != ncclSuccess)                                                                         \
+            return set_error(-11, std::string(#expr) + ": " + ncclGetErrorString(e_));                 \
+    } while (0)
+
+// launch a kernel template over the lanes-per-vertex parameter
+#define LAUNCH_G(G, KERNEL, grid, stream, ...)                                                         \
+    do {                                                                                               \
+        switch (G) {                                                                                   \
+            case 1: hipLaunchKernelGGL((KERNEL<T, 1>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 2: hipLaunchKernelGGL((KERNEL<T, 2>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL((KERNEL<T, 4>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((KERNEL<T, 8>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+        }                                                                                              \
+    } while (0)
+#define LAUNCH_GM(G, KERNEL, MODE, grid, stream, ...)                                                  \
+    do {                                                                                               \
+        switch (G) {                                                                                   \
+            case 1: hipLaunchKernelGGL((KERNEL<T, 1, MODE>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 2: hipLaunchKernelGGL((KERNEL<T, 2, MODE>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL((KERNEL<T, 4, MODE>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((KERNEL<T, 8, MODE>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+        }                                                                                              \
+    } while (0)
+
+struct IEngine {
+    virtual ~IEngine() {}
+    virtual int set_graph(const tsgo_graph& g) = 0;
+    virtual int optimize(int iterations, tsgo_stats* st) = 0;
+    virtual int get_vertices(double* out) = 0;
+    virtual int linearize(double* diag, double* grad, double* chi2) = 0;
+    virtual int solve_step(double* delta, double* chi2, int* iters) = 0;
+    virtual int time_kernel(int which, int reps, double* us, double* bytes) = 0;
+    ncclComm_t comm = nullptr;
+};
+
+constexpr int kChunk = 16;   // PCG iterations per captured hipGraph (even: the state ring has 2 slots)
+
+template <typename T> struct Engine : IEngine {
+    tsgo_config cfg;
+    Problem pr;
+    hipStream_t stream = nullptr;
+    std::vector<void*> allocs;
+    bool have_graph_data = false;
+    double ms_setup = 0;
+
+    // device
+    T *ps = nullptr, *theta = nullptr, *lmrec = nullptr, *gauge_p = nullptr, *gauge_l = nullptr;
+    Table<T> tp{}, tl{}, to{};
+    T *part = nullptr, *dp = nullptr, *minv = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *x = nullptr, *zc = nullptr;
+    T *sbuf = nullptr, *tvec = nullptr, *dl = nullptr, *gpart[2] = {nullptr, nullptr}, *npart = nullptr;
+    CgState<T>* st[2] = {nullptr, nullptr};
+    CgState<T>* h_state = nullptr;     // pinned
+    T* h_scratch = nullptr;            // pinned, partial sums
+    int nbP = 0, nbL = 0, nbC = 0;
+    hipGraphExec_t cg_graph = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    int predicted_cg = 0;
+
+    explicit Engine(const tsgo_config& c) : cfg(c) {}
+
+    ~Engine() override { release(); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+
+    void release() {
+        if (cg_graph) { (void)hipGraphExecDestroy(cg_graph); cg_graph = nullptr; }
+        for (void* a : allocs) (void)hipFree(a);
+        allocs.clear();
+        if (h_state) { (void)hipHostFree(h_state); h_state = nullptr; }
+        if (h_scratch) { (void)hipHostFree(h_scratch); h_scratch = nullptr; }
+        have_graph_data = false;
+    }
+
+    int init() {
+        HIP_OK(hipSetDevice(cfg.device));
+        HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        for (auto& e : ev) HIP_OK(hipEventCreate(&e));
+        return 0;
+    }
+
+    template <typename U> int dalloc(U** out, size_t n) {
+        void* ptr = nullptr;
+        HIP_OK(hipMalloc(&ptr, std::max<size_t>(n, 1) * sizeof(U)));
+        allocs.push_back(ptr);
+        *out = (U*)ptr;
+        return 0;
+    }
+    int upload_T(T** out, const double* src, size_t n) {
+        if (int rc = dalloc(out, n)) return rc;
+        if (n == 0) return 0;
+        std::vector<T> tmp(n);
+        for (size_t k = 0; k < n; ++k) tmp[k] = (T)src[k];
+        HIP_OK(hipMemcpy(*out, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
+        return 0;
+    }
+    int upload_u32(const uint32_t** out, const std::vector<uint32_t>& v) {
+        uint32_t* d = nullptr;
+        if (int rc = dalloc(&d, v.size())) return rc;
+        if (!v.empty()) HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        *out = d;
+        return 0;
+    }
+    int upload_table(Table<T>& t, const SellTable& h, int dyn_planes) {
+        t.slots = h.slots(); t.n_slices = h.n_slices; t.n_vertices = h.n_vertices;
+        if (int rc = upload_u32(&t.row_off, h.row_off)) return rc;
+        if (int rc = upload_u32(&t.idx, h.idx)) return rc;
+        T* stp = nullptr;
+        if (int rc = upload_T(&stp, h.planes.data(), h.planes.size())) return rc;
+        t.st = stp;
+        if (int rc = dalloc(&t.dyn, (size_t)dyn_planes * h.slots())) return rc;
+        HIP_OK(hipMemset(t.dyn, 0, std::max<size_t>((size_t)dyn_planes * h.slots(), 1) * sizeof(T)));
+        return 0;
+    }
+
+    int set_graph(const tsgo_graph& g) override {
+        const auto t0 = std::chrono::steady_clock::now();
+        HIP_OK(hipSetDevice(cfg.device));
+        release();
+        BuildOptions bo; bo.rank = cfg.rank; bo.world = cfg.world; bo.lanes_per_pose = cfg.lanes_per_pose; bo.lanes_per_lm = cfg.lanes_per_lm;
+        const std::string err = build_problem(g, bo, pr);
+        if (!err.empty()) return set_error(-2, "tsgo_set_graph: " + err);
+        const int P = pr.P, L = pr.L;
+        if (P == 0) return set_error(-2, "tsgo_set_graph: the graph has no Se2 vertex");
+        // state
+        std::vector<double> ps_h((size_t)P * 4), th_h(P);
+        for (int i = 0; i < P; ++i) {
+            th_h[i] = pr.pose_xyt[3 * (size_t)i + 2];
+            ps_h[4 * (size_t)i] = pr.pose_xyt[3 * (size_t)i]; ps_h[4 * (size_t)i + 1] = pr.pose_xyt[3 * (size_t)i + 1];
+            ps_h[4 * (size_t)i + 2] = std::cos(th_h[i]); ps_h[4 * (size_t)i + 3] = std::sin(th_h[i]);
+        }
+        if (int rc = upload_T(&ps, ps_h.data(), ps_h.size())) return rc;
+        if (int rc = upload_T(&theta, th_h.data(), th_h.size())) return rc;
+        std::vector<double> lm_h((size_t)std::max(L, 1) * kLmRec, 0.0);
+        for (int l = 0; l < L; ++l) { lm_h[(size_t)l * kLmRec] = pr.lm_xy[2 * (size_t)l]; lm_h[(size_t)l * kLmRec + 1] = pr.lm_xy[2 * (size_t)l + 1]; }
+        if (int rc = upload_T(&lmrec, lm_h.data(), lm_h.size())) return rc;
+        if (int rc = upload_T(&gauge_p, pr.gauge_p.data(), pr.gauge_p.size())) return rc;
+        if (int rc = upload_T(&gauge_l, pr.gauge_l.data(), pr.gauge_l.size())) return rc;
+        if (int rc = upload_table(tp, pr.by_pose, 4)) return rc;
+        if (int rc = upload_table(tl, pr.by_lm, 4)) return rc;
+        if (int rc = upload_table(to, pr.odom, 3)) return rc;
+        nbP = (tp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
+        nbL = (tl.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
+        nbC = (P + kBlock - 1) / kBlock;
+        if (int rc = dalloc(&part, (size_t)P * 18 + nbP)) return rc;
+        if (int rc = dalloc(&dp, (size_t)P * 6)) return rc;
+        if (int rc = dalloc(&minv, (size_t)P * 6)) return rc;
+        if (int rc = dalloc(&r, (size_t)P * 3)) return rc;
+        if (int rc = dalloc(&p, (size_t)P * 3)) return rc;
+        if (int rc = dalloc(&q, (size_t)P * 3)) return rc;
+        if (int rc = dalloc(&x, (size_t)P * 3)) return rc;
+        if (int rc = dalloc(&zc, (size_t)P * kPoseRec)) return rc;
+        HIP_OK(hipMemset(zc, 0, (size_t)P * kPoseRec * sizeof(T)));
+        if (int rc = dalloc(&sbuf, (size_t)P * 3 + nbP)) return rc;
+        if (int rc = dalloc(&tvec, (size_t)std::max(L, 1) * 2)) return rc;
+        if (int rc = dalloc(&dl, (size_t)std::max(L, 1) * 2)) return rc;
+        HIP_OK(hipMemset(dl, 0, (size_t)std::max(L, 1) * 2 * sizeof(T)));
+        for (int k = 0; k < 2; ++k) { if (int rc = dalloc(&gpart[k], nbC)) return rc; if (int rc = dalloc(&st[k], 1)) return rc; }
+        if (int rc = dalloc(&npart, (size_t)nbC + std::max(nbL, 1))) return rc;
+        HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
+        HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, nbC) + nbL + 8)));
+        HIP_OK(hipDeviceSynchronize());
+        have_graph_data = true;
+        predicted_cg = 0;
+        if (cfg.use_graphs && pr.world == 1) { if (int rc = capture_cg_graph()) return rc; }
+        ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    }
+
+    // ---- launches --------------------------------------------------------------------------------
+    void launch_lin() {
+        if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l);
+        LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18);
+    }
+    void launch_finalize() {
+        hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0]);
+    }
+    void launch_matvec(int slot) {   // S * (vector in zc) -> sbuf, dot partials behind it
+        if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, tvec, st[slot], T(0), dl, npart);
+        LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot]);
+    }
+    void launch_cg_update(int slot) {
+        const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
+        hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[slot], nbC,
+                           gpart[slot ^ 1], st[slot], st[slot ^ 1], minv, r, p, q, x, zc, tol2, cfg.pcg_max_iters);
+    }
+    int allreduce(T* buf, size_t n) {
+        if (pr.world <= 1) return 0;
+        if (!comm) return set_error(-12, "world > 1 but tsgo_comm_init was not called");
+        NCCL_OK(ncclAllReduce(buf, buf, n, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream));
+        return 0;
+    }
+    int capture_cg_graph() {
+        hipGraph_t graph = nullptr;
+        HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
+        for (int j = 0; j < kChunk; ++j) { launch_matvec(j & 1); launch_cg_update(j & 1); }
+        HIP_OK(hipStreamEndCapture(stream, &graph));
+        HIP_OK(hipGraphInstantiate(&cg_graph, graph, nullptr, nullptr, 0));
+        HIP_OK(hipGraphDestroy(graph));
+        return 0;
+    }
+
+    // one linearisation; chi2 on the host
+    int do_linearize(double* chi2) {
+        launch_lin();
+        if (int rc = allreduce(part, (size_t)pr.P * 18 + nbP)) return rc;
+        launch_finalize();
+        HIP_OK(hipMemcpyAsync(h_scratch, part + (size_t)pr.P * 18, sizeof(T) * nbP, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        double s = 0;
+        for (int k = 0; k < nbP; ++k) s += (double)h_scratch[k];
+        *chi2 = s;
+        return 0;
+    }
+
+    // PCG until the device state says done.  The state ring is at slot 0 on entry and on exit.
+    int do_solve(int* iters, int* fail) {
+        int launched = 0;
+        int burst = std::max(1, (int)(0.9 * predicted_cg) / kChunk);    // chunks before the first look
+        for (;;) {
+            for (int b = 0; b < burst; ++b) {
+                if (cg_graph) HIP_OK(hipGraphLaunch(cg_graph, stream));
+                else for (int j = 0; j < kChunk; ++j) {
+                    launch_matvec(j & 1);
+                    if (int rc = allreduce(sbuf, (size_t)pr.P * 3 + nbP)) return rc;
+                    launch_cg_update(j & 1);
+                }
+                launched += kChunk;
+            }
+            burst = 1;
+            HIP_OK(hipMemcpyAsync(h_state, st[0], sizeof(CgState<T>), hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            if (h_state->done) break;
+            if (launched > cfg.pcg_max_iters + 2 * kChunk) return set_error(-20, "PCG did not terminate");
+        }
+        *iters = h_state->iters; *fail = h_state->fail;
+        predicted_cg = h_state->iters;
+        return 0;
+    }
+
+    // landmarks: dl = u - Dl^-1 W^T x (+ optional update); poses: update; returns ||delta||
+    int do_backsub_update(T step, double* delta_norm) {
+        const int P = pr.P;
+        hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, zc);
+        if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 1, nbL, stream, tl, zc, lmrec, tvec, st[0], step, dl, npart + nbC);
+        hipLaunchKernelGGL((k_pose_update<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, ps, theta, step, npart);
+        const int nl = tl.n_slices > 0 ? nbL : 0;
+        HIP_OK(hipMemcpyAsync(h_scratch, npart, sizeof(T) * (size_t)(nbC + nl), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        double np2 = 0, nl2 = 0;
+        for (int k = 0; k < nbC; ++k) np2 += (double)h_scratch[k];
+        for (int k = 0; k < nl; ++k) nl2 += (double)h_scratch[nbC + k];
+        if (pr.world > 1) {      // landmark deltas are shard-local
+            T* d = part;          // reuse as a one-element device scratch
+            T v = (T)nl2;
+            HIP_OK(hipMemcpyAsync(d, &v, sizeof(T), hipMemcpyHostToDevice, stream));
+            if (int rc = allreduce(d, 1)) return rc;
+            HIP_OK(hipMemcpyAsync(&v, d, sizeof(T), hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            nl2 = (double)v;
+        }
+        *delta_norm = std::sqrt(np2 + nl2);
+        return 0;
+    }
+
+    int optimize(int iterations, tsgo_stats* out) override {
+        if (!have_graph_data) return set_error(-3, "tsgo_optimize: no graph set");
+        HIP_OK(hipSetDevice(cfg.device));
+        tsgo_stats s; std::memset(&s, 0, sizeof(s));
+        s.n_pose = pr.P; s.n_lm = pr.L_total; s.n_odom_edges = pr.n_odom_edges_total; s.n_lm_edges = pr.n_lm_edges_total;
+        s.ms_setup = ms_setup;
+        double prevErr = -1; int penalty = 0;
+        s.stop_reason = TSGO_STOP_CAP;
+        const auto wall0 = std::chrono::steady_clock::now();
+        for (int it = 0; it < iterations; ++it) {
+            double err = 0; float ms = 0;
+            HIP_OK(hipEventRecord(ev[0], stream));
+            if (int rc = do_linearize(&err)) return rc;
+            HIP_OK(hipEventRecord(ev[1], stream));
+            if (it < TSGO_MAX_TRACE) s.chi2[it] = err;
+            s.iterations_run = it + 1;
+            if (prevErr > 0 && err > prevErr) {                          // OptimizerCpu.h:140-153
+                if (++penalty > 2) { s.stop_reason = TSGO_STOP_WORSE; break; }
+            } else penalty = 0;
+            int cg = 0, fail = 0;
+            if (int rc = do_solve(&cg, &fail)) return rc;
+            HIP_OK(hipEventRecord(ev[2], stream));
+            if (it < TSGO_MAX_TRACE) s.pcg_iters[it] = cg;
+            s.pcg_iters_total += cg;
+            if (fail == 1) { s.stop_reason = TSGO_STOP_SOLVER; break; }
+            double nrm = 0;
+            if (int rc = do_backsub_update((T)kStepScale, &nrm)) return rc;   // :159-165
+            HIP_OK(hipEventRecord(ev[3], stream));
+            HIP_OK(hipEventSynchronize(ev[3]));
+            HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[1])); s.ms_linearize += ms;
+            HIP_OK(hipEventElapsedTime(&ms, ev[1], ev[2])); s.ms_solve += ms;
+            HIP_OK(hipEventElapsedTime(&ms, ev[2], ev[3])); s.ms_update += ms;
+            s.last_delta_norm = nrm;
+            if (std::fabs(err - prevErr) < kPlateauTol) { s.stop_reason = TSGO_STOP_PLATEAU; break; }   // :167-171
+            if (nrm < kDeltaTol) { s.stop_reason = TSGO_STOP_CONVERGED; break; }                        // :173-177
+            prevErr = err;                                                                              // :179
+        }
+        s.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+        if (out) *out = s;
+        return 0;
+    }
+
+    int get_vertices(double* out) override {
+        if (!have_graph_data) return set_error(-3, "tsgo_get_vertices: no graph set");
+        HIP_OK(hipSetDevice(cfg.device));
+        const int P = pr.P, L = pr.L;
+        std::vector<T> hp((size_t)P * 4), hl((size_t)std::max(L, 1) * kLmRec);
+        HIP_OK(hipMemcpy(hp.data(), ps, hp.size() * sizeof(T), hipMemcpyDeviceToHost));
+        if (L) HIP_OK(hipMemcpy(hl.data(), lmrec, (size_t)L * kLmRec * sizeof(T), hipMemcpyDeviceToHost));
+        for (int i = 0; i < P; ++i) {
+            const int v = pr.pose_vertex[i];
+            out[3 * (size_t)v] = hp[4 * (size_t)i]; out[3 * (size_t)v + 1] = hp[4 * (size_t)i + 1];
+            out[3 * (size_t)v + 2] = std::atan2((double)hp[4 * (size_t)i + 3], (double)hp[4 * (size_t)i + 2]);   // SerializeGraphFuncCpu.h:28
+        }
+        for (int l = 0; l < L; ++l) {
+            const int v = pr.lm_vertex[l];
+            out[3 * (size_t)v] = hl[(size_t)l * kLmRec]; out[3 * (size_t)v + 1] = hl[(size_t)l * kLmRec + 1]; out[3 * (size_t)v + 2] = 0;
+        }
+        return 0;
+    }
+
+    int linearize(double* diag, double* grad, double* chi2) override {
+        if (!have_graph_data) return set_error(-3, "tsgo_linearize: no graph set");
+        HIP_OK(hipSetDevice(cfg.device));
+        if (int rc = do_linearize(chi2)) return rc;
+        const int P = pr.P, L = pr.L;
+        std::vector<T> hpart((size_t)P * 18), hl((size_t)std::max(L, 1) * kLmRec);
+        HIP_OK(hipMemcpy(hpart.data(), part, hpart.size() * sizeof(T), hipMemcpyDeviceToHost));
+        if (L) HIP_OK(hipMemcpy(hl.data(), lmrec, (size_t)L * kLmRec * sizeof(T), hipMemcpyDeviceToHost));
+        std::memset(diag, 0, sizeof(double) * 9 * (size_t)pr.n_vertices);
+        std::memset(grad, 0, sizeof(double) * 3 * (size_t)pr.n_vertices);
+        for (int i = 0; i < P; ++i) {
+            const T* o = &hpart[(size_t)i * 18];
+            double* d = diag + 9 * (size_t)pr.pose_vertex[i]; double* g = grad + 3 * (size_t)pr.pose_vertex[i];
+            d[0] = o[0]; d[1] = d[3] = o[1]; d[2] = d[6] = o[2]; d[4] = o[3]; d[5] = d[7] = o[4]; d[8] = o[5];
+            g[0] = o[6]; g[1] = o[7]; g[2] = o[8];
+        }
+        for (int l = 0; l < L; ++l) {
+            const T* o = &hl[(size_t)l * kLmRec];
+            double ixx = o[2], ixy = o[3], iyy = o[4], dxx, dxy, dyy;
+            inv_sym2<double>(ixx, ixy, iyy, dxx, dxy, dyy);       // Dl = (Dl^-1)^-1
+            double* d = diag + 9 * (size_t)pr.lm_vertex[l]; double* g = grad + 3 * (size_t)pr.lm_vertex[l];
+            d[0] = dxx; d[1] = d[3] = dxy; d[4] = dyy;
+            g[0] = dxx * o[5] + dxy * o[6]; g[1] = dxy * o[5] + dyy * o[6];
+        }
+        return 0;
+    }
+
+    int solve_step(double* delta, double* chi2, int* iters) override {
+        if (!have_graph_data) return set_error(-3, "tsgo_solve_step: no graph set");
+        HIP_OK(hipSetDevice(cfg.device));
+        if (int rc = do_linearize(chi2)) return rc;
+        int cg = 0, fail = 0;
+        if (int rc = do_solve(&cg, &fail)) return rc;
+        if (iters) *iters = cg;
+        // back-substitute with step 0: state untouched (theta is re-derived from the same cos/sin)
+        double nrm = 0;
+        if (int rc = do_backsub_update((T)0, &nrm)) return rc;
+        const int P = pr.P, L = pr.L;
+        std::vector<T> hx((size_t)P * 3), hd((size_t)std::max(L, 1) * 2);
+        HIP_OK(hipMemcpy(hx.data(), x, hx.size() * sizeof(T), hipMemcpyDeviceToHost));
+        if (L) HIP_OK(hipMemcpy(hd.data(), dl, (size_t)L * 2 * sizeof(T), hipMemcpyDeviceToHost));
+        std::memset(delta, 0, sizeof(double) * 3 * (size_t)pr.n_vertices);
+        for (int i = 0; i < P; ++i) for (int k = 0; k < 3; ++k) delta[3 * (size_t)pr.pose_vertex[i] + k] = hx[(size_t)i * 3 + k];
+        for (int l = 0; l < L; ++l) for (int k = 0; k < 2; ++k) delta[3 * (size_t)pr.lm_vertex[l] + k] = hd[(size_t)l * 2 + k];
+        return fail == 1 ? set_error(-21, "PCG breakdown") : 0;
+    }
+
+    // which: 0 schur_lm, 1 schur_pose, 2 cg_update, 3 lin_lm, 4 lin_pose, 5 one whole PCG iteration
+    int time_kernel(int which, int reps, double* us, double* bytes) override {
+        if (!have_graph_data) return set_error(-3, "tsgo_time_kernel: no graph set");
+        HIP_OK(hipSetDevice(cfg.device));
+        double chi2;
+        if (int rc = do_linearize(&chi2)) return rc;      // valid operands; state slot 0 says "not done"
+        const double s = sizeof(T);
+        const double El = (double)pr.n_lm_edges, P = pr.P, L = pr.L;
+        double od = 0; for (uint32_t e : pr.odom.edge) od += e != kNoEdge;
+        const double b_lm = El * (4 + 4 * s) + P * 5 * s + L * 5 * s;
+        const double b_pose = El * (4 + 4 * s) + L * 2 * s + P * (5 + 6 + 3) * s + od * (4 + 3 * s + 3 * s);
+        const double b_upd = P * (3 + 3 + 6 + 4 * 3 * 2 - 3) * s;   // sz, z in; minv in; r p q x in+out (x,r,p,q), z out
+        const double b_linlm = El * (4 + 4 * s + 4 * s) + El * 4 * s * 0 + P * 4 * s + L * (2 + 5) * s;
+        const double b_linpose = El * (4 + 4 * s + 4 * s) + L * 7 * s + P * (4 + 18) * s + od * (4 + 9 * s + 3 * s);
+        for (int pass = 0; pass < 2; ++pass) {
+            const int n = pass == 0 ? 3 : reps;
+            HIP_OK(hipEventRecord(ev[0], stream));
+            for (int k = 0; k < n; ++k) {
+                switch (which) {
+                    case 0: if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, tvec, st[0], T(0), dl, npart); break;
+                    case 1: LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[0]); break;
+                    case 2: {   // state slot 1 is never written here, slot 0 stays "iters = 0, not done"
+                        const T tol2 = (T)0;
+                        hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[0], nbC,
+                                           gpart[1], st[0], st[1], minv, r, p, q, x, zc, tol2, 1 << 30);
+                        break;
+                    }
+                    case 3: if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l); break;
+                    case 4: LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18); break;
+                    default: launch_matvec(0); launch_cg_update(0); launch_matvec(1); launch_cg_update(1); break;
+                }
+            }
+            HIP_OK(hipEventRecord(ev[1], stream));
+            HIP_OK(hipEventSynchronize(ev[1]));
+            if (pass == 1) {
+                float ms = 0;
+                HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[1]));
+                const double per = which >= 5 ? 2.0 * n : (double)n;
+                *us = 1e3 * ms / per;
+            }
+        }
+        const double tab[6] = {b_lm, b_pose, b_upd, b_linlm, b_linpose, b_lm + b_pose + b_upd};
+        *bytes = tab[std::min(std::max(which, 0), 5)];
+        // leave a consistent state behind
+        return do_linearize(&chi2);
+    }
+};
+
+}  // namespace
+
+struct tsgo_optimizer {
+    tsgo_config cfg;
+    IEngine* eng = nullptr;
+};
+
+extern "C" {
+
+int tsgo_create(const tsgo_config* cfg, tsgo_optimizer** out) {
+    if (!out) return tsgo::set_error(-1, "tsgo_create: null argument");
+    tsgo_config c;
+    if (cfg) c = *cfg; else tsgo_default_config(&c);
+    if (c.precision != 32 && c.precision != 64) return tsgo::set_error(-1, "tsgo_create: precision must be 32 or 64");
+    if (c.world < 1) c.world = 1;
+    if (c.pcg_rel_tol <= 0) c.pcg_rel_tol = 1e-10;
+    if (c.pcg_max_iters <= 0) c.pcg_max_iters = 20000;
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev <= 0)
+        return tsgo::set_error(-10, "tsgo_create: no HIP device is visible; this library has no CPU fallback");
+    if (c.device < 0 || c.device >= n_dev) return tsgo::set_error(-10, "tsgo_create: device ordinal out of range");
+    auto* o = new tsgo_optimizer();
+    o->cfg = c;
+    int rc;
+    if (c.precision == 64) { auto* e = new Engine<double>(c); rc = e->init(); o->eng = e; }
+    else { auto* e = new Engine<float>(c); rc = e->init(); o->eng = e; }
+    if (rc) { delete o->eng; delete o; return rc; }
+    *out = o;
+    return 0;
+}
+
+void tsgo_destroy(tsgo_optimizer* o) {
+    if (!o) return;
+    if (o->eng && o->eng->comm) (void)ncclCommDestroy(o->eng->comm);
+    delete o->eng;
+    delete o;
+}
+
+int tsgo_set_graph(tsgo_optimizer* o, const tsgo_graph* g) {
+    if (!o || !g) return tsgo::set_error(-1, "tsgo_set_graph: null argument");
+    return o->eng->set_graph(*g);
+}
+int tsgo_optimize(tsgo_optimizer* o, int32_t iterations, tsgo_stats* st) {
+    if (!o) return tsgo::set_error(-1, "tsgo_optimize: null argument");
+    return o->eng->optimize(iterations, st);
+}
+int tsgo_get_vertices(tsgo_optimizer* o, double* out) {
+    if (!o || !out) return tsgo::set_error(-1, "tsgo_get_vertices: null argument");
+    return o->eng->get_vertices(out);
+}
+int tsgo_linearize(tsgo_optimizer* o, double* diag, double* grad, double* chi2) {
+    if (!o || !diag || !grad || !chi2) return tsgo::set_error(-1, "tsgo_linearize: null argument");
+    return o->eng->linearize(diag, grad, chi2);
+}
+int tsgo_solve_step(tsgo_optimizer* o, double* delta, double* chi2, int32_t* iters) {
+    if (!o || !delta || !chi2) return tsgo::set_error(-1, "tsgo_solve_step: null argument");
+    return o->eng->solve_step(delta, chi2, iters);
+}
+int tsgo_time_kernel(tsgo_optimizer* o, int32_t which, int32_t reps, double* us, double* bytes) {
+    if (!o || !us || !bytes || reps <= 0) return tsgo::set_error(-1, "tsgo_time_kernel: bad argument");
+    return o->eng->time_kernel(which, reps, us, bytes);
+}
+int tsgo_comm_unique_id(uint8_t id_out[128]) {
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");
+    ncclUniqueId id;
+    NCCL_OK(ncclGetUniqueId(&id));
+    std::memcpy(id_out, &id, 128);
+    return 0;
+}
+int tsgo_comm_init(tsgo_optimizer* o, const uint8_t id_in[128]) {
+    if (!o || !id_in) return tsgo::set_error(-1, "tsgo_comm_init: null argument");
+    HIP_OK(hipSetDevice(o->cfg.device));
+    ncclUniqueId id;
+    std::memcpy(&id, id_in, 128);
+    NCCL_OK(ncclCommInitRank(&o->eng->comm, o->cfg.world, id, o->cfg.rank));
+    return 0;
+}
+
+}  // extern "C"

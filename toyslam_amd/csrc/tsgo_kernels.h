@@ -1,0 +1,453 @@
+// tsgo_kernels.h — the hand-written gfx950 kernels of the Gauss-Newton hot path.
+//
+// Execution shape shared by every "table" kernel: one 64-lane wavefront per SELL slice, G lanes
+// (1, 2, 4 or 8) cooperating on one vertex, a workgroup of 256 threads = 4 slices.  A lane walks the
+// rows of its slice; every per-slot plane load is a fully coalesced 64-lane row (512 B in f64), the
+// only irregular access is ONE small gathered record per slot (a 64-B pose record or a 16-B
+// landmark vector).  Sums over a vertex's edges stay in registers and finish with G-lane xor
+// shuffles: no atomics anywhere, results are bitwise reproducible.  MFMA is not used: there is no
+// dense contraction on this path (blocks are 3x3 / 3x2 and the arithmetic intensity is < 1 flop/B).
+//
+// What each kernel replaces in the reference's CUDA pipeline (function, not code):
+//   lin_lm / lin_pose   ProcessSe2Point2s + ProcessSe2s  (remote/cuda/optimizer/kernels/
+//                       KernelSe2Point2.cu:46-155, KernelSe2.cu:37-112): residual, Jacobian, Huber,
+//                       J^T W J / J^T W r — but into block-sparse storage by segmented register sums
+//                       instead of 25-36 atomicAdds per edge into a dense n x n H
+//   pose_finalize       FixVertices + Negativate (KernelCommon.cu:6-25,62-71) + preconditioner
+//   schur_lm/schur_pose + cg_update   the linear solve (cuSOLVER geqrf/ormqr + cuBLAS trsm,
+//                       remote/cuda/solver/SolverCudaQr.h:51-79) as implicit-Schur PCG
+//   pose_update / schur_lm<BACKSUB>   Update (KernelCommon.cu:27-60)
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "tsgo_math.h"
+
+namespace tsgo {
+
+constexpr int kBlock = 256;             // threads per workgroup = 4 wavefronts
+constexpr int kWavesPerBlock = kBlock / 64;
+constexpr uint32_t kDirMask = 0x80000000u;
+
+// record layouts (in units of T)
+constexpr int kPoseRec = 8;   // zc: v0 v1 v2 c s . . .      (the vector CG multiplies + the pose's cos/sin)
+constexpr int kLmRec = 8;     // lmrec: lx ly ixx ixy iyy ux uy .   (landmark, Dl^-1, u = Dl^-1 g_l)
+
+template <typename T> struct CgState { T gamma_old, alpha_old, gamma0, pad; int iters, done, fail, pad2; };
+
+template <typename T> struct Table {       // one SELL table on the device
+    const uint32_t* row_off; const uint32_t* idx; const T* st; T* dyn; size_t slots; int n_slices; int n_vertices;
+};
+
+template <typename T, int G> __device__ __forceinline__ T group_sum(T v) {
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+template <typename T> __device__ __forceinline__ T wave_sum(T v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m);
+    return v;
+}
+
+// Sum over the workgroup; every thread gets the result.  `red` = kWavesPerBlock T's of LDS.
+template <typename T> __device__ __forceinline__ T block_sum(T v, T* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6;
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[w] = v;
+    __syncthreads();
+    T s = red[0];
+#pragma unroll
+    for (int k = 1; k < kWavesPerBlock; ++k) s += red[k];
+    return s;
+}
+
+// Fixed-order sum of n partials by a whole workgroup (n is a few hundred).
+template <typename T> __device__ __forceinline__ T block_sum_array(const T* a, int n, T* red) {
+    T v = 0;
+    for (int k = threadIdx.x; k < n; k += kBlock) v += a[k];
+    return block_sum(v, red);
+}
+
+// ------------------------------------------------------------------------------------------------
+// K1 lin_lm: per landmark — landmark-side linearisation of its LM edges.
+//   reads : slot planes zx zy w0 w1 + pose index (coalesced), pose state ps[i] = (x,y,c,s) (gather)
+//   writes: slot planes a0 a1 ppx ppy (lm-major copy), lmrec[l][2..6] = Dl^-1, u
+template <typename T, int G>
+__global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restrict__ ps, T* __restrict__ lmrec,
+                                                   const T* __restrict__ gauge_l) {
+    const int slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    if (slice >= tb.n_slices) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int VPS = 64 / G;
+    const int l = slice * VPS + lane / G;
+    const bool valid = l < tb.n_vertices;
+    const int lc = valid ? l : tb.n_vertices - 1;
+    const T lx = lmrec[(size_t)lc * kLmRec], ly = lmrec[(size_t)lc * kLmRec + 1];
+    T dxx = 0, dxy = 0, dyy = 0, g0 = 0, g1 = 0;
+    const size_t S = tb.slots;
+    const uint32_t r0 = tb.row_off[slice], r1 = tb.row_off[slice + 1];
+    for (uint32_t row = r0; row < r1; ++row) {
+        const size_t k = (size_t)row * 64 + lane;
+        const uint32_t i = tb.idx[k];
+        const T zx = tb.st[k], zy = tb.st[S + k], w0 = tb.st[2 * S + k], w1 = tb.st[3 * S + k];
+        const T* q = ps + (size_t)i * 4;
+        const T x = q[0], y = q[1], c = q[2], s = q[3];
+        const LmLin<T> o = lm_linearize<T>(x, y, c, s, lx, ly, zx, zy, w0, w1);
+        tb.dyn[k] = o.a0; tb.dyn[S + k] = o.a1; tb.dyn[2 * S + k] = o.ppx; tb.dyn[3 * S + k] = o.ppy;
+        dxx += o.a0 * c * c + o.a1 * s * s; dxy += (o.a0 - o.a1) * c * s; dyy += o.a0 * s * s + o.a1 * c * c;
+        const T f0 = o.a0 * o.e0, f1 = o.a1 * o.e1;
+        g0 -= c * f0 - s * f1; g1 -= s * f0 + c * f1;
+    }
+    dxx = group_sum<T, G>(dxx); dxy = group_sum<T, G>(dxy); dyy = group_sum<T, G>(dyy);
+    g0 = group_sum<T, G>(g0); g1 = group_sum<T, G>(g1);
+    if (valid && (lane % G) == 0) {
+        const T ga = gauge_l[l];
+        T ixx, ixy, iyy;
+        inv_sym2<T>(dxx + ga, dxy, dyy + ga, ixx, ixy, iyy);
+        T* o = lmrec + (size_t)l * kLmRec;
+        o[2] = ixx; o[3] = ixy; o[4] = iyy; o[5] = ixx * g0 + ixy * g1; o[6] = ixy * g0 + iyy * g1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K2 lin_pose: per pose — pose-side linearisation of its LM edges + its ODOM rows.
+//   writes: slot planes (pose-major copy), ODOM weights, part[i][18] = Dp(6) g(3) Sd(6) Wu(3) in the
+//           world frame, one chi^2 partial per workgroup
+template <typename T, int G>
+__global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, const T* __restrict__ ps,
+                                                     const T* __restrict__ lmrec, const T* __restrict__ gauge_p,
+                                                     int pose_first, int pose_last, T* __restrict__ part,
+                                                     T* __restrict__ chi_part) {
+    __shared__ T red[kWavesPerBlock];
+    const int slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const bool live = slice < tb.n_slices;
+    const int lane = threadIdx.x & 63;
+    constexpr int VPS = 64 / G;
+    const int i = slice * VPS + lane / G;
+    const bool valid = live && i < tb.n_vertices;
+    T chi = 0;
+    if (live) {
+        const int ic = valid ? i : tb.n_vertices - 1;
+        const T x0 = ps[(size_t)ic * 4], y0 = ps[(size_t)ic * 4 + 1], c = ps[(size_t)ic * 4 + 2], s = ps[(size_t)ic * 4 + 3];
+        T sA0 = 0, sA1 = 0, sAv0 = 0, sAv1 = 0, sVV = 0, ge0 = 0, ge1 = 0, get = 0;
+        T K00 = 0, K01 = 0, K11 = 0, Kv0 = 0, Kv1 = 0, vKv = 0, wu0 = 0, wu1 = 0, wut = 0;
+        {
+            const size_t S = tb.slots;
+            const uint32_t r0 = tb.row_off[slice], r1 = tb.row_off[slice + 1];
+            for (uint32_t row = r0; row < r1; ++row) {
+                const size_t k = (size_t)row * 64 + lane;
+                const uint32_t l = tb.idx[k];
+                const T zx = tb.st[k], zy = tb.st[S + k], w0 = tb.st[2 * S + k], w1 = tb.st[3 * S + k];
+                const T* lr = lmrec + (size_t)l * kLmRec;
+                const T lx = lr[0], ly = lr[1], nxx = lr[2], nxy = lr[3], nyy = lr[4], ux = lr[5], uy = lr[6];
+                const LmLin<T> o = lm_linearize<T>(x0, y0, c, s, lx, ly, zx, zy, w0, w1);
+                tb.dyn[k] = o.a0; tb.dyn[S + k] = o.a1; tb.dyn[2 * S + k] = o.ppx; tb.dyn[3 * S + k] = o.ppy;
+                chi += o.rho;
+                const T v0 = o.ppy, v1 = -o.ppx;
+                sA0 += o.a0; sA1 += o.a1; sAv0 += o.a0 * v0; sAv1 += o.a1 * v1; sVV += o.a0 * v0 * v0 + o.a1 * v1 * v1;
+                ge0 += o.a0 * o.e0; ge1 += o.a1 * o.e1; get += o.a0 * o.e0 * v0 + o.a1 * o.e1 * v1;
+                const T n00 = c * c * nxx + 2 * c * s * nxy + s * s * nyy;
+                const T n01 = c * s * (nyy - nxx) + (c * c - s * s) * nxy;
+                const T n11 = s * s * nxx - 2 * c * s * nxy + c * c * nyy;
+                const T k00 = o.a0 * n00 * o.a0, k01 = o.a0 * n01 * o.a1, k11 = o.a1 * n11 * o.a1;
+                K00 += k00; K01 += k01; K11 += k11;
+                const T kv0 = k00 * v0 + k01 * v1, kv1 = k01 * v0 + k11 * v1;
+                Kv0 += kv0; Kv1 += kv1; vKv += v0 * kv0 + v1 * kv1;
+                const T t0 = c * ux + s * uy, t1 = c * uy - s * ux;
+                wu0 += o.a0 * t0; wu1 += o.a1 * t1; wut += o.a0 * t0 * v0 + o.a1 * t1 * v1;
+            }
+        }
+        // ODOM rows (listed at both endpoints; chi^2 counted at id1)
+        T od0 = 0, od1 = 0, od2 = 0, og0 = 0, og1 = 0, og2 = 0;
+        {
+            const size_t S = od.slots;
+            const uint32_t r0 = od.row_off[slice], r1 = od.row_off[slice + 1];
+            for (uint32_t row = r0; row < r1; ++row) {
+                const size_t k = (size_t)row * 64 + lane;
+                const uint32_t raw = od.idx[k];
+                const bool second = (raw & kDirMask) != 0;
+                const uint32_t j = raw & ~kDirMask;
+                T mi[6], w[3];
+#pragma unroll
+                for (int m = 0; m < 6; ++m) mi[m] = od.st[(size_t)m * S + k];
+#pragma unroll
+                for (int m = 0; m < 3; ++m) w[m] = od.st[(size_t)(6 + m) * S + k];
+                const T* oq = ps + (size_t)j * 4;
+                const T xj = oq[0], yj = oq[1], cj = oq[2], sj = oq[3];
+                const OdomLin<T> o = second ? odom_linearize<T>(xj, yj, cj, sj, x0, y0, c, s, mi, w)
+                                            : odom_linearize<T>(x0, y0, c, s, xj, yj, cj, sj, mi, w);
+                od.dyn[k] = o.a[0]; od.dyn[S + k] = o.a[1]; od.dyn[2 * S + k] = o.a[2];
+                od0 += o.a[0]; od1 += o.a[1]; od2 += o.a[2];
+                const T sg = second ? T(-1) : T(1);
+                og0 += sg * o.a[0] * o.e[0]; og1 += sg * o.a[1] * o.e[1]; og2 += sg * o.a[2] * o.e[2];
+                // a padding slot has w = 0: rho = 0 there
+                if (!second) chi += o.rho;
+            }
+        }
+#define GS(v) v = group_sum<T, G>(v)
+        GS(sA0); GS(sA1); GS(sAv0); GS(sAv1); GS(sVV); GS(ge0); GS(ge1); GS(get);
+        GS(K00); GS(K01); GS(K11); GS(Kv0); GS(Kv1); GS(vKv); GS(wu0); GS(wu1); GS(wut);
+        GS(od0); GS(od1); GS(od2); GS(og0); GS(og1); GS(og2);
+#undef GS
+        if (valid && (lane % G) == 0) {
+            const T ga = (i >= pose_first && i < pose_last) ? gauge_p[i] : T(0);
+            T* o = part + (size_t)i * 18;
+            o[0] = c * c * sA0 + s * s * sA1 + od0 + ga; o[1] = c * s * (sA0 - sA1); o[3] = s * s * sA0 + c * c * sA1 + od1 + ga;
+            o[2] = -(c * sAv0 - s * sAv1); o[4] = -(s * sAv0 + c * sAv1); o[5] = sVV + od2 + ga;
+            o[6] = c * ge0 - s * ge1 + og0; o[7] = s * ge0 + c * ge1 + og1; o[8] = -get + og2;
+            o[9] = c * c * K00 - 2 * c * s * K01 + s * s * K11;
+            o[10] = c * s * (K00 - K11) + (c * c - s * s) * K01;
+            o[12] = s * s * K00 + 2 * c * s * K01 + c * c * K11;
+            o[11] = -(c * Kv0 - s * Kv1); o[13] = -(s * Kv0 + c * Kv1); o[14] = vKv;
+            o[15] = -(c * wu0 - s * wu1); o[16] = -(s * wu0 + c * wu1); o[17] = wut;
+        }
+    }
+    const T total = block_sum<T>(chi, red);
+    if (threadIdx.x == 0) chi_part[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3 pose_finalize: per pose (thread = pose) — M = Dp - Sd (gauge already inside Dp), M^-1, reduced
+// right-hand side, CG start (x = p = q = 0, r = b~, z = M^-1 r) and gamma_0 partials.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __restrict__ part, const T* __restrict__ ps,
+                                                          T* __restrict__ dp, T* __restrict__ minv, T* __restrict__ r,
+                                                          T* __restrict__ p, T* __restrict__ q, T* __restrict__ x,
+                                                          T* __restrict__ zc, T* __restrict__ gpart,
+                                                          CgState<T>* __restrict__ st0) {
+    __shared__ T red[kWavesPerBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    T g = 0;
+    if (i < P) {
+        const T* o = part + (size_t)i * 18;
+        T m[6], mi[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { dp[(size_t)i * 6 + k] = o[k]; m[k] = o[k] - o[9 + k]; }
+        inv_sym3<T>(m, mi);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) minv[(size_t)i * 6 + k] = mi[k];
+        const T r0 = o[6] - o[15], r1 = o[7] - o[16], r2 = o[8] - o[17];
+        T z0, z1, z2;
+        sym3_mul<T>(mi, r0, r1, r2, z0, z1, z2);
+        r[(size_t)i * 3] = r0; r[(size_t)i * 3 + 1] = r1; r[(size_t)i * 3 + 2] = r2;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { p[(size_t)i * 3 + k] = 0; q[(size_t)i * 3 + k] = 0; x[(size_t)i * 3 + k] = 0; }
+        T* zr = zc + (size_t)i * kPoseRec;
+        zr[0] = z0; zr[1] = z1; zr[2] = z2; zr[3] = ps[(size_t)i * 4 + 2]; zr[4] = ps[(size_t)i * 4 + 3];
+        g = r0 * z0 + r1 * z1 + r2 * z2;
+    }
+    const T total = block_sum<T>(g, red);
+    if (threadIdx.x == 0) gpart[blockIdx.x] = total;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        CgState<T> s; s.gamma_old = 0; s.alpha_old = 0; s.gamma0 = 0; s.pad = 0; s.iters = 0; s.done = 0; s.fail = 0; s.pad2 = 0;
+        *st0 = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// KA schur_lm: per landmark — t = Dl^-1 W^T v, v being the vector held in zc[.][0..2].
+//   MODE 0: write t.   MODE 1 (back-substitution): dl = u - t, landmark += step * dl, |dl|^2 partial.
+// HOT KERNEL 1 of the PCG iteration.
+template <typename T, int G, int MODE>
+__global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __restrict__ zc, T* __restrict__ lmrec,
+                                                     T* __restrict__ t, const CgState<T>* __restrict__ st,
+                                                     T step, T* __restrict__ dl_out, T* __restrict__ norm_part) {
+    __shared__ T red[kWavesPerBlock];
+    if (MODE == 0 && st->done) return;
+    const int slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const bool live = slice < tb.n_slices;
+    const int lane = threadIdx.x & 63;
+    constexpr int VPS = 64 / G;
+    const int l = slice * VPS + lane / G;
+    T nrm = 0;
+    if (live) {
+        T acc0 = 0, acc1 = 0;
+        const size_t S = tb.slots;
+        const uint32_t r0 = tb.row_off[slice], r1 = tb.row_off[slice + 1];
+#pragma unroll 2
+        for (uint32_t row = r0; row < r1; ++row) {
+            const size_t k = (size_t)row * 64 + lane;
+            const uint32_t i = tb.idx[k];
+            const T a0 = tb.dyn[k], a1 = tb.dyn[S + k], ppx = tb.dyn[2 * S + k], ppy = tb.dyn[3 * S + k];
+            const T* zr = zc + (size_t)i * kPoseRec;
+            const T v0 = zr[0], v1 = zr[1], v2 = zr[2], c = zr[3], s = zr[4];
+            const T vt0 = c * v0 + s * v1, vt1 = c * v1 - s * v0;
+            const T m0 = a0 * (ppy * v2 - vt0), m1 = a1 * (-vt1 - ppx * v2);
+            acc0 += c * m0 - s * m1; acc1 += s * m0 + c * m1;
+        }
+        acc0 = group_sum<T, G>(acc0); acc1 = group_sum<T, G>(acc1);
+        if (l < tb.n_vertices && (lane % G) == 0) {
+            T* lr = lmrec + (size_t)l * kLmRec;
+            const T ixx = lr[2], ixy = lr[3], iyy = lr[4];
+            const T t0 = ixx * acc0 + ixy * acc1, t1 = ixy * acc0 + iyy * acc1;
+            if (MODE == 0) { t[(size_t)l * 2] = t0; t[(size_t)l * 2 + 1] = t1; }
+            else {
+                const T d0 = lr[5] - t0, d1 = lr[6] - t1;
+                dl_out[(size_t)l * 2] = d0; dl_out[(size_t)l * 2 + 1] = d1;
+                lr[0] += step * d0; lr[1] += step * d1;
+                nrm = d0 * d0 + d1 * d1;
+            }
+        }
+    }
+    if (MODE == 1) {
+        const T total = block_sum<T>(nrm, red);
+        if (threadIdx.x == 0) norm_part[blockIdx.x] = total;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// KB schur_pose: per pose — out = Hpp v - W t (this shard's share), partial dot (out, v).
+// HOT KERNEL 2 of the PCG iteration.
+template <typename T, int G>
+__global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od, const T* __restrict__ zc,
+                                                       const T* __restrict__ t, const T* __restrict__ dp,
+                                                       int pose_first, int pose_last, T* __restrict__ out,
+                                                       T* __restrict__ dot_part, const CgState<T>* __restrict__ st) {
+    __shared__ T red[kWavesPerBlock];
+    if (st->done) return;
+    const int slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const bool live = slice < tb.n_slices;
+    const int lane = threadIdx.x & 63;
+    constexpr int VPS = 64 / G;
+    const int i = slice * VPS + lane / G;
+    T dot = 0;
+    if (live) {
+        const bool valid = i < tb.n_vertices;
+        const int ic = valid ? i : tb.n_vertices - 1;
+        const T* zr = zc + (size_t)ic * kPoseRec;
+        const T v0 = zr[0], v1 = zr[1], v2 = zr[2], c = zr[3], s = zr[4];
+        T acc0 = 0, acc1 = 0, acc2 = 0;
+        {
+            const size_t S = tb.slots;
+            const uint32_t r0 = tb.row_off[slice], r1 = tb.row_off[slice + 1];
+#pragma unroll 2
+            for (uint32_t row = r0; row < r1; ++row) {
+                const size_t k = (size_t)row * 64 + lane;
+                const uint32_t l = tb.idx[k];
+                const T a0 = tb.dyn[k], a1 = tb.dyn[S + k], ppx = tb.dyn[2 * S + k], ppy = tb.dyn[3 * S + k];
+                const T tx = t[(size_t)l * 2], ty = t[(size_t)l * 2 + 1];
+                const T t0 = a0 * (c * tx + s * ty), t1 = a1 * (c * ty - s * tx);
+                acc0 += t0; acc1 += t1; acc2 += t0 * ppy - t1 * ppx;
+            }
+        }
+        T o0 = 0, o1 = 0, o2 = 0;
+        {
+            const size_t S = od.slots;
+            const uint32_t r0 = od.row_off[slice], r1 = od.row_off[slice + 1];
+            for (uint32_t row = r0; row < r1; ++row) {
+                const size_t k = (size_t)row * 64 + lane;
+                const uint32_t j = od.idx[k] & ~kDirMask;
+                const T* zj = zc + (size_t)j * kPoseRec;
+                o0 -= od.dyn[k] * zj[0]; o1 -= od.dyn[S + k] * zj[1]; o2 -= od.dyn[2 * S + k] * zj[2];
+            }
+        }
+        acc0 = group_sum<T, G>(acc0); acc1 = group_sum<T, G>(acc1); acc2 = group_sum<T, G>(acc2);
+        o0 = group_sum<T, G>(o0); o1 = group_sum<T, G>(o1); o2 = group_sum<T, G>(o2);
+        if (valid && (lane % G) == 0) {
+            o0 += c * acc0 - s * acc1; o1 += s * acc0 + c * acc1; o2 -= acc2;
+            if (i >= pose_first && i < pose_last) {
+                T d0, d1, d2;
+                sym3_mul<T>(dp + (size_t)i * 6, v0, v1, v2, d0, d1, d2);
+                o0 += d0; o1 += d1; o2 += d2;
+            }
+            out[(size_t)i * 3] = o0; out[(size_t)i * 3 + 1] = o1; out[(size_t)i * 3 + 2] = o2;
+            dot = o0 * v0 + o1 * v1 + o2 * v2;
+        }
+    }
+    const T total = block_sum<T>(dot, red);
+    if (threadIdx.x == 0) dot_part[blockIdx.x] = total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// KC cg_update: per pose — the vector half of a Chronopoulos-Gear PCG iteration (one global
+// reduction point per iteration instead of two).  Every workgroup first sums the partials of
+// delta = (S z, z) (from KB) and gamma = (r, z) (from the previous KC / pose_finalize) in a fixed
+// order, then:  beta = gamma/gamma_old, alpha = gamma/(delta - beta*gamma/alpha_old),
+//   p = z + beta p,  q = S z + beta q,  x += alpha p,  r -= alpha q,  z = M^-1 r.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cg_update(int P, const T* __restrict__ sz, const T* __restrict__ dot_part,
+                                                      int n_dot, const T* __restrict__ gpart_in, int n_g,
+                                                      T* __restrict__ gpart_out, const CgState<T>* __restrict__ st_in,
+                                                      CgState<T>* __restrict__ st_out, const T* __restrict__ minv,
+                                                      T* __restrict__ r, T* __restrict__ p, T* __restrict__ q,
+                                                      T* __restrict__ x, T* __restrict__ zc, T tol2, int max_iters) {
+    __shared__ T red[kWavesPerBlock];
+    const CgState<T> s = *st_in;
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    if (s.done) { if (writer) *st_out = s; return; }
+    const T delta = block_sum_array<T>(dot_part, n_dot, red);
+    const T gamma = block_sum_array<T>(gpart_in, n_g, red);
+    const T gamma0 = s.iters == 0 ? gamma : s.gamma0;
+    CgState<T> n = s; n.gamma0 = gamma0;
+    if (!(gamma > tol2 * gamma0) || s.iters >= max_iters) {      // converged (or cap, or NaN): x is final
+        n.done = 1; n.fail = (gamma != gamma) ? 1 : ((gamma > tol2 * gamma0) ? 2 : 0);
+        if (writer) *st_out = n;
+        return;
+    }
+    T beta, alpha;
+    if (s.iters == 0) { beta = 0; alpha = gamma / delta; }
+    else { beta = gamma / s.gamma_old; alpha = gamma / (delta - beta * gamma / s.alpha_old); }
+    if (!(alpha > 0) || !(alpha < T(1e300))) {                    // breakdown: keep x, flag it
+        n.done = 1; n.fail = 1;
+        if (writer) *st_out = n;
+        return;
+    }
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    T g = 0;
+    if (i < P) {
+        T rr[3];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t j = (size_t)i * 3 + k;
+            const T zk = zc[(size_t)i * kPoseRec + k];
+            const T pk = zk + beta * p[j];
+            const T qk = sz[j] + beta * q[j];
+            p[j] = pk; q[j] = qk;
+            x[j] += alpha * pk;
+            rr[k] = r[j] - alpha * qk;
+            r[j] = rr[k];
+        }
+        T z0, z1, z2;
+        sym3_mul<T>(minv + (size_t)i * 6, rr[0], rr[1], rr[2], z0, z1, z2);
+        T* zr = zc + (size_t)i * kPoseRec;
+        zr[0] = z0; zr[1] = z1; zr[2] = z2;
+        g = rr[0] * z0 + rr[1] * z1 + rr[2] * z2;
+    }
+    const T total = block_sum<T>(g, red);
+    if (threadIdx.x == 0) gpart_out[blockIdx.x] = total;
+    if (writer) { n.gamma_old = gamma; n.alpha_old = alpha; n.iters = s.iters + 1; *st_out = n; }
+}
+
+// x -> zc[.][0..2] (the landmark pass reads its vector from zc)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pack_x(int P, const T* __restrict__ x, T* __restrict__ zc) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < P) { zc[(size_t)i * kPoseRec] = x[(size_t)i * 3]; zc[(size_t)i * kPoseRec + 1] = x[(size_t)i * 3 + 1]; zc[(size_t)i * kPoseRec + 2] = x[(size_t)i * 3 + 2]; }
+}
+
+// pose (+)= step * delta: VertexSe2::Update (remote/graph/vertex/VertexSe2.h:16-27) with the 0.2 of
+// OptimizerCpu.h:164 — theta = atan2(sin, cos) + step*dth, translation added in the world frame.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_pose_update(int P, const T* __restrict__ x, T* __restrict__ ps,
+                                                        T* __restrict__ theta, T step, T* __restrict__ norm_part) {
+    __shared__ T red[kWavesPerBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    T nrm = 0;
+    if (i < P) {
+        const T d0 = x[(size_t)i * 3], d1 = x[(size_t)i * 3 + 1], d2 = x[(size_t)i * 3 + 2];
+        nrm = d0 * d0 + d1 * d1 + d2 * d2;
+        if (step != T(0)) {
+            T* q = ps + (size_t)i * 4;
+            const T th = atan2(q[3], q[2]) + step * d2;
+            q[0] += step * d0; q[1] += step * d1; q[2] = cos(th); q[3] = sin(th);
+            theta[i] = th;
+        }
+    }
+    const T total = block_sum<T>(nrm, red);
+    if (threadIdx.x == 0) norm_part[blockIdx.x] = total;
+}
+
+}  // namespace tsgo

@@ -1,0 +1,105 @@
+// tsgo_math.h — per-edge arithmetic of the Gauss-Newton hot path, shared by the HIP kernels
+// (tsgo_kernels.hip) and by host code.  Everything is expressed in the POSE FRAME of the edge's
+// first vertex, which is what lets one LM edge be stored as four numbers (a0, a1, ppx, ppy).
+//
+// Reference behaviour restated here (paths relative to the ToySlam tree):
+//   LM edge   remote/graph/edge/EdgeSe2Point2d.h:27-70   e = R^T (l - t) - z,  A = [-R^T | v],  B = R^T
+//             with v = (ppy, -ppx), (ppx, ppy) = R^T (l - t)   (A(0,2) = ppy, A(1,2) = -ppx, :58,:61)
+//   ODOM edge remote/graph/edge/EdgeSe2.h:23-38          e = (D02, D12, atan2(D10, D00)),
+//             D = meas^-1 (T1^-1 T2),  A = -I, B = +I (constant, :35-37)
+//   Huber     remote/optimizer/OptimizerCpu.h:36-46      on chi^2, delta = 1.5
+//   blocks    remote/optimizer/OptimizerCpu.h:88-119     Omega_w = w_huber * Omega (diagonal on the wire,
+//             remote/serialization/DeserializeGraph.h:123-147)
+#pragma once
+
+#if defined(__HIPCC__)
+#define TSGO_HD __host__ __device__ __forceinline__
+#else
+#define TSGO_HD inline
+#endif
+
+#include <cmath>
+
+namespace tsgo {
+
+constexpr double kHuberDelta = 1.5;      // OptimizerCpu.h:92
+constexpr double kStepScale = 0.2;       // OptimizerCpu.h:164
+constexpr double kGauge = 1e6;           // OptimizerCpu.h:136
+constexpr double kPlateauTol = 1e-3;     // OptimizerCpu.h:167
+constexpr double kDeltaTol = 1e-3;       // OptimizerCpu.h:173
+
+template <typename T> TSGO_HD void huber(T chi2, T& rho, T& w) {
+    const T d = T(kHuberDelta), d2 = d * d;
+    if (chi2 <= d2) { rho = chi2; w = T(1); }
+    else { const T sq = sqrt(chi2); rho = T(2) * sq * d - d2; w = d / sq; }
+}
+
+// One LM edge seen from pose (x, y, c = cos th, s = sin th) and landmark (lx, ly); z = (r cos phi,
+// r sin phi) is precomputed on the host.  Outputs the four numbers every later pass needs.
+template <typename T> struct LmLin { T a0, a1, ppx, ppy, e0, e1, rho; };
+
+template <typename T>
+TSGO_HD LmLin<T> lm_linearize(T x, T y, T c, T s, T lx, T ly, T zx, T zy, T w0, T w1) {
+    LmLin<T> o;
+    const T dx = lx - x, dy = ly - y;
+    o.ppx = c * dx + s * dy;
+    o.ppy = c * dy - s * dx;
+    o.e0 = o.ppx - zx;
+    o.e1 = o.ppy - zy;
+    const T chi2 = w0 * o.e0 * o.e0 + w1 * o.e1 * o.e1;
+    T hw;
+    huber(chi2, o.rho, hw);
+    o.a0 = hw * w0;
+    o.a1 = hw * w1;
+    return o;
+}
+
+// ODOM edge: pose1 (x1,y1,c1,s1) -> pose2; mi = top two rows of meas^-1 (row-major 2x3).
+template <typename T> struct OdomLin { T a[3], e[3], rho; };
+
+template <typename T>
+TSGO_HD OdomLin<T> odom_linearize(T x1, T y1, T c1, T s1, T x2, T y2, T c2, T s2, const T* mi, const T* w) {
+    OdomLin<T> o;
+    const T dx = x2 - x1, dy = y2 - y1;
+    const T px = c1 * dx + s1 * dy, py = c1 * dy - s1 * dx;       // R1^T (t2 - t1)
+    const T cc = c1 * c2 + s1 * s2, ss = c1 * s2 - s1 * c2;       // R1^T R2 = [[cc,-ss],[ss,cc]]
+    o.e[0] = mi[0] * px + mi[1] * py + mi[2];
+    o.e[1] = mi[3] * px + mi[4] * py + mi[5];
+    o.e[2] = atan2(mi[3] * cc + mi[4] * ss, mi[0] * cc + mi[1] * ss);
+    const T chi2 = w[0] * o.e[0] * o.e[0] + w[1] * o.e[1] * o.e[1] + w[2] * o.e[2] * o.e[2];
+    T hw;
+    huber(chi2, o.rho, hw);
+    o.a[0] = hw * w[0]; o.a[1] = hw * w[1]; o.a[2] = hw * w[2];
+    return o;
+}
+
+// Symmetric 2x2 inverse (xx, xy, yy).  A singular block (vertex without edges) maps to zero, which
+// leaves that vertex where it is (the reference's rank-revealing QR does the same).
+template <typename T> TSGO_HD void inv_sym2(T xx, T xy, T yy, T& ixx, T& ixy, T& iyy) {
+    const T det = xx * yy - xy * xy;
+    if (!(fabs(det) > T(0))) { ixx = ixy = iyy = T(0); return; }
+    const T r = T(1) / det;
+    ixx = yy * r; ixy = -xy * r; iyy = xx * r;
+}
+
+// Symmetric 3x3 inverse, storage (00, 01, 02, 11, 12, 22).
+template <typename T> TSGO_HD void inv_sym3(const T* m, T* o) {
+    const T c00 = m[3] * m[5] - m[4] * m[4];
+    const T c01 = m[2] * m[4] - m[1] * m[5];
+    const T c02 = m[1] * m[4] - m[2] * m[3];
+    const T det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    if (!(fabs(det) > T(0))) { for (int k = 0; k < 6; ++k) o[k] = T(0); return; }
+    const T r = T(1) / det;
+    o[0] = c00 * r; o[1] = c01 * r; o[2] = c02 * r;
+    o[3] = (m[0] * m[5] - m[2] * m[2]) * r;
+    o[4] = (m[1] * m[2] - m[0] * m[4]) * r;
+    o[5] = (m[0] * m[3] - m[1] * m[1]) * r;
+}
+
+template <typename T> TSGO_HD void sym3_mul(const T* m, T v0, T v1, T v2, T& o0, T& o1, T& o2) {
+    o0 = m[0] * v0 + m[1] * v1 + m[2] * v2;
+    o1 = m[1] * v0 + m[3] * v1 + m[4] * v2;
+    o2 = m[2] * v0 + m[4] * v1 + m[5] * v2;
+}
+
+}  // namespace tsgo

@@ -1,0 +1,109 @@
+"""Python host side of the device optimizer.
+
+HipOptimizer wraps the C ABI one-to-one.  GraphOptimizer mirrors the reference's in-process
+python/optimizer/graph_optimizer.py:11-92 (`GraphOptimizer(graph).optimize(iterations)`) but runs the
+`cpu eigen` rules of remote/optimizer/OptimizerCpu.h:25-183 on the GPU.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from .graph import GraphArrays
+
+STOP = {0: "cap", 1: "worse", 2: "plateau", 3: "converged", 4: "solver_failed"}
+
+
+class HipOptimizer:
+    def __init__(self, device=0, precision=64, pcg_rel_tol=1e-10, pcg_max_iters=20000, lanes_per_pose=0,
+                 lanes_per_lm=0, use_graphs=True, rank=0, world=1):
+        self.lib = _lib.hip_lib()
+        cfg = _lib.tsgo_config()
+        self.lib.tsgo_default_config(C.byref(cfg))
+        cfg.device, cfg.precision, cfg.pcg_rel_tol, cfg.pcg_max_iters = device, precision, pcg_rel_tol, pcg_max_iters
+        cfg.lanes_per_pose, cfg.lanes_per_lm, cfg.use_graphs = lanes_per_pose, lanes_per_lm, int(use_graphs)
+        cfg.rank, cfg.world = rank, world
+        self.cfg = cfg
+        self.h = C.c_void_p()
+        _lib.check(self.lib, self.lib.tsgo_create(C.byref(cfg), C.byref(self.h)), "tsgo_create")
+        self.n_vertices = 0
+
+    def close(self):
+        if self.h:
+            self.lib.tsgo_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_graph(self, g: GraphArrays):
+        cg = g.c_struct()
+        _lib.check(self.lib, self.lib.tsgo_set_graph(self.h, C.byref(cg)), "tsgo_set_graph")
+        self.n_vertices = len(g.v_id)
+
+    def optimize(self, iterations):
+        st = _lib.tsgo_stats()
+        _lib.check(self.lib, self.lib.tsgo_optimize(self.h, iterations, C.byref(st)), "tsgo_optimize")
+        n = min(st.iterations_run, _lib.TSGO_MAX_TRACE)
+        return dict(iters=st.iterations_run, stop=STOP[st.stop_reason], chi2=np.array(st.chi2[:n]),
+                    cg_iters=np.array(st.pcg_iters[:n]), delta_norm=st.last_delta_norm, ms_total=st.ms_total,
+                    ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup,
+                    n_pose=st.n_pose, n_lm=st.n_lm, n_odom_edges=st.n_odom_edges, n_lm_edges=st.n_lm_edges,
+                    cg_total=st.pcg_iters_total)
+
+    def vertices(self):
+        out = np.zeros((self.n_vertices, 3))
+        _lib.check(self.lib, self.lib.tsgo_get_vertices(self.h, out.ctypes.data), "tsgo_get_vertices")
+        return out
+
+    def linearize(self):
+        diag = np.zeros((self.n_vertices, 9)); grad = np.zeros((self.n_vertices, 3)); chi = C.c_double()
+        _lib.check(self.lib, self.lib.tsgo_linearize(self.h, diag.ctypes.data, grad.ctypes.data, C.byref(chi)),
+                   "tsgo_linearize")
+        return diag, grad, chi.value
+
+    def solve_step(self):
+        d = np.zeros((self.n_vertices, 3)); chi = C.c_double(); it = C.c_int32()
+        _lib.check(self.lib, self.lib.tsgo_solve_step(self.h, d.ctypes.data, C.byref(chi), C.byref(it)),
+                   "tsgo_solve_step")
+        return dict(delta=d, chi2=chi.value, cg_iters=it.value)
+
+    def time_kernel(self, which, reps=50):
+        us = C.c_double(); nbytes = C.c_double()
+        _lib.check(self.lib, self.lib.tsgo_time_kernel(self.h, which, reps, C.byref(us), C.byref(nbytes)),
+                   "tsgo_time_kernel")
+        return us.value, nbytes.value
+
+    def comm_unique_id(self):
+        buf = (C.c_uint8 * 128)()
+        _lib.check(self.lib, self.lib.tsgo_comm_unique_id(buf), "tsgo_comm_unique_id")
+        return bytes(buf)
+
+    def comm_init(self, uid: bytes):
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        _lib.check(self.lib, self.lib.tsgo_comm_init(self.h, buf), "tsgo_comm_init")
+
+
+class GraphOptimizer:
+    """Same call shape as python/optimizer/graph_optimizer.py:11-20: GraphOptimizer(graph).optimize(n)."""
+
+    def __init__(self, graph, **kw):
+        self.graph = graph
+        self.kw = kw
+        self.last = None
+
+    def optimize(self, iterations, lr=0.2):
+        if lr != 0.2:
+            raise ValueError("the remote optimizer's step is fixed at 0.2 (remote/optimizer/OptimizerCpu.h:164)")
+        arr = GraphArrays.from_optgraph(self.graph)
+        opt = HipOptimizer(**self.kw)
+        try:
+            opt.set_graph(arr)
+            self.last = opt.optimize(iterations)
+            arr.write_back(self.graph, opt.vertices())
+        finally:
+            opt.close()
+        return self.last

@@ -1,0 +1,157 @@
+#!/usr/bin/env python3
+"""bench.py — edges/s per Gauss-Newton iteration on the BASELINE.json workload.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3_100k|c2_10k|c5_1m] [--precision 64]
+  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is ONE full Gauss-Newton iteration on the device-resident graph: linearise every edge
+(residual, Jacobian, Huber, block accumulation), solve H delta = b by implicit-Schur PCG to the
+configured tolerance, update every vertex.  Inputs are resident in HBM before the timed region
+(tsgo_set_graph is outside it).  value = (ODOM + LM edges) * K / wall time of K steps, max over ranks.
+
+N > 1 shards ONE graph by edge set (strong scaling): landmark ranges per rank, pose state replicated,
+RCCL all-reduce of the pose partials once per GN iteration and of the Schur product once per PCG
+iteration (multi-GPU).
+
+Extra objects on the JSON line: `roofline` (dominant kernel, algorithmic bytes / hipEvent time measured
+here) and `cpu_baseline` (the CPU twin of the same math on the host cores; rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+KERNELS = {0: "k_schur_lm", 1: "k_schur_pose", 2: "k_cg_update", 3: "k_lin_lm", 4: "k_lin_pose"}
+
+
+def cpu_baseline(g, threads):
+    """One full GN iteration (iteration 0) of the SAME graph by the CPU twin (oracle/oracle_sparse.cpp):
+    same layout, same Schur PCG, same tolerance.  kind = "port": the reference's own dense algorithm
+    cannot run this size (O(n^2) memory)."""
+    from oracle import oracle
+    from tests import util
+    oracle.set_threads(threads)
+    o = util.to_oracle(g)
+    t0 = time.time()
+    r = oracle.sparse_optimize(o, 1, pcg_tol=ARGS.pcg_tol)
+    dt = time.time() - t0
+    return {"value": len(g.e_type) / dt, "unit": "edges/s per GN iter", "cores": threads, "kind": "port",
+            "sample": "GN iteration 0 of the same %s graph: linearise + %d PCG iterations (tol %g) + update, %.1f s"
+                      % (ARGS.workload, int(r["cg_iters"][0]), ARGS.pcg_tol, dt),
+            "pcg_iters": int(r["cg_iters"][0]), "seconds": dt}
+
+
+def main():
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != ARGS.gpus:
+        if world == 1 and ARGS.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with that many processes" % ARGS.gpus)
+    from toyslam_amd import synth
+    from toyslam_amd.optimizer import HipOptimizer
+
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    g = synth.make_config(ARGS.workload, seed=0)
+    n_edges = len(g.e_type)
+    opt = HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol, rank=rank, world=world,
+                       use_graphs=not ARGS.no_graphs, lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm)
+    if world > 1:
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid = torch.tensor(list(opt.comm_unique_id()), dtype=torch.uint8, device="cuda")
+        dist.broadcast(uid, 0)
+        opt.comm_init(bytes(uid.cpu().tolist()))
+    opt.set_graph(g)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    chi2, cg = [], []
+    for _ in range(ARGS.warmup):
+        r = opt.optimize(1); chi2 += list(r["chi2"]); cg += list(r["cg_iters"])
+    barrier()
+    t0 = time.perf_counter()
+    ms_lin = ms_solve = ms_upd = 0.0
+    for _ in range(ARGS.steps):
+        r = opt.optimize(1); chi2 += list(r["chi2"]); cg += list(r["cg_iters"])
+        ms_lin += r["ms_linearize"]; ms_solve += r["ms_solve"]; ms_upd += r["ms_update"]
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    timed_cg = cg[ARGS.warmup:]
+
+    out = None
+    if rank == 0:
+        # dominant kernel: the one with the largest share of a GN iteration
+        n_cg = float(np.mean(timed_cg)) if timed_cg else 0.0
+        shares = {}
+        for which in (0, 1, 2, 3, 4):
+            us, nbytes = opt.time_kernel(which, reps=200)
+            per_iter = us * (n_cg if which < 3 else 1.0)
+            shares[which] = (per_iter, us, nbytes)
+        dom = max(shares, key=lambda k: shares[k][0])
+        _, us, nbytes = shares[dom]
+        achieved = nbytes / (us * 1e-6) / 1e9
+        out = {
+            "metric": "edges/sec per GN iter", "value": n_edges * ARGS.steps / dt, "unit": "edges/s",
+            "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup, "ms_per_step": 1e3 * dt / ARGS.steps,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64" if ARGS.precision == 64 else "f32", "data": "synthetic",
+            "config": {"workload": "%s: %d poses / %d landmarks / %d ODOM + %d LM edges, seeded synthetic 2-D SLAM graph"
+                                   % (ARGS.workload, g.n_poses, g.n_landmarks, int((g.e_type == 0).sum()), int((g.e_type == 1).sum())),
+                       "solver": "implicit-Schur PCG (Chronopoulos-Gear), block-Jacobi on the Schur diagonal, rel tol %g" % ARGS.pcg_tol,
+                       "parallelism": "edge-sharded x%d" % world if world > 1 else "single GPU",
+                       "hipgraph": not ARGS.no_graphs},
+            "gn_iters_per_s": ARGS.steps / dt,
+            "pcg_iters_per_gn_iter": n_cg,
+            "chi2_first_last": [chi2[0], chi2[-1]],
+            "ms_per_step_device": {"linearize": ms_lin / ARGS.steps, "solve": ms_solve / ARGS.steps, "update": ms_upd / ARGS.steps},
+            "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "us_per_launch": us, "algorithmic_bytes_per_launch": nbytes,
+                         "all_kernels_us": {KERNELS[k]: shares[k][1] for k in shares}},
+        }
+        if world == 1 and not ARGS.no_cpu:
+            out["cpu_baseline"] = cpu_baseline(g, ARGS.cpu_threads or min(16, len(os.sched_getaffinity(0))))
+    opt.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="c3_100k")
+    ap.add_argument("--precision", type=int, default=64)
+    ap.add_argument("--pcg-tol", dest="pcg_tol", type=float, default=1e-8)
+    ap.add_argument("--no-graphs", dest="no_graphs", action="store_true")
+    ap.add_argument("--no-cpu", dest="no_cpu", action="store_true")
+    ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0)
+    ap.add_argument("--lanes-pose", dest="lanes_pose", type=int, default=0)
+    ap.add_argument("--lanes-lm", dest="lanes_lm", type=int, default=0)
+    ARGS = ap.parse_args()
+    main()

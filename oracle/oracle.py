@@ -26,6 +26,20 @@ def build(force=False):
     return so
 
 
+def default_threads():
+    """Threads for the twin's OpenMP loops: the process's CPU share, capped at 8 (a GPU box shows every
+    logical CPU of the host; oversubscribed OpenMP barriers spin for milliseconds)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(8, n))
+
+
+def set_threads(n):
+    lib().oracle_set_threads(int(n))
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -43,6 +57,9 @@ def lib():
         L.oracle_sparse_optimize.argtypes = _GRAPH + [f64p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
                                                       ALLREDUCE_FN, C.c_void_p, f64p, i32p, i32p, i32p, f64p,
                                                       f64p, f64p]
+        L.oracle_set_threads.argtypes = [C.c_int]
+        L.oracle_set_threads.restype = None
+        L.oracle_set_threads(default_threads())
         _LIB = L
     return _LIB
 

@@ -14,6 +14,8 @@
 //
 // GN loop rules: remote/optimizer/OptimizerCpu.h:80-180.  Per-edge math: tsgo_math.h (which cites
 // EdgeSe2Point2d.h / EdgeSe2.h).  Vertex update: VertexSe2.h:16-27, Vertex2d.h:16-19.
+#include <omp.h>
+
 #include <cmath>
 #include <cstdint>
 #include <cstring>
@@ -39,6 +41,7 @@ struct Twin {
     std::vector<double> part;                       // per pose 18: Dp(6) g(3) Sd(6) Wu(3); + 1 chi2 at the end
     std::vector<double> dp, minv, r, z, p, q, x, s; // per pose
     double chi2 = 0;
+    std::vector<double> gscratch;
 
     void allreduce(double* b, int64_t n) { if (hook && pr.world > 1) hook(b, n, hook_ctx); }
 
@@ -161,8 +164,8 @@ struct Twin {
     // K3: M = Dp + gauge - Sd, M^-1, reduced rhs, CG start vectors.  Returns gamma0 = r^T M^-1 r.
     double finalize() {
         chi2 = part[(size_t)P * 18];
-        double gamma = 0;
-        #pragma omp parallel for schedule(static) reduction(+ : gamma)
+        std::vector<double> gi(P, 0.0);     // summed serially below: every shard must get the same bits
+        #pragma omp parallel for schedule(static)
         for (int i = 0; i < P; ++i) {
             const double* o18 = &part[(size_t)i * 18];
             double m[6];
@@ -171,8 +174,10 @@ struct Twin {
             tsgo::inv_sym3(m, &minv[6 * (size_t)i]);
             for (int k = 0; k < 3; ++k) { r[3 * (size_t)i + k] = o18[6 + k] - o18[15 + k]; x[3 * (size_t)i + k] = 0; p[3 * (size_t)i + k] = 0; q[3 * (size_t)i + k] = 0; }
             tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
-            for (int k = 0; k < 3; ++k) gamma += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
+            for (int k = 0; k < 3; ++k) gi[i] += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
         }
+        double gamma = 0;
+        for (int i = 0; i < P; ++i) gamma += gi[i];
         return gamma;
     }
 
@@ -256,8 +261,8 @@ struct Twin {
             if (it == 0) { beta = 0; alpha = gamma / delta; }
             else { beta = gamma / gamma_old; alpha = gamma / (delta - beta * gamma / alpha_old); }
             if (!(alpha > 0) || !std::isfinite(alpha)) { *ok = false; break; }
-            double gnew = 0;
-            #pragma omp parallel for schedule(static) reduction(+ : gnew)
+            std::vector<double>& gi = gscratch; gi.assign(P, 0.0);
+            #pragma omp parallel for schedule(static)
             for (int i = 0; i < P; ++i) {
                 for (int k = 0; k < 3; ++k) {
                     const size_t j = 3 * (size_t)i + k;
@@ -265,8 +270,10 @@ struct Twin {
                     x[j] += alpha * p[j]; r[j] -= alpha * q[j];
                 }
                 tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
-                for (int k = 0; k < 3; ++k) gnew += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
+                for (int k = 0; k < 3; ++k) gi[i] += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
             }
+            double gnew = 0;
+            for (int i = 0; i < P; ++i) gnew += gi[i];       // serial: identical on every shard
             gamma_old = gamma; alpha_old = alpha; gamma = gnew;
         }
         return it;
@@ -326,6 +333,9 @@ tsgo_graph make_view(int nV, const uint32_t* v_id, const uint32_t* v_type, const
 #define GRAPH_PASS nV, v_id, v_type, v_pos, nE, e_type, e_ids, e_meas, e_inf, nF, fixed
 
 extern "C" {
+
+// OpenMP threads used by the twin's loops (a GPU box exposes far more logical CPUs than its share).
+void oracle_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
 
 // One Gauss-Newton step at the given state: delta (3 per vertex, graph order; landmarks of other
 // shards are left 0), chi2, PCG iterations.  hook/ctx: all-reduce(sum) over shards, may be NULL.

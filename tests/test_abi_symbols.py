@@ -1,0 +1,59 @@
+"""The C-ABI libraries load on a CPU-only box and export every symbol include/tsgo.h declares."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from toyslam_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "tsgo.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(tsgo_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_declares_what_the_bindings_expect():
+    names = declared_symbols()
+    for s in _lib.HOST_SYMBOLS + _lib.DEVICE_SYMBOLS:
+        assert s in names, s
+    assert set(names) == set(_lib.HOST_SYMBOLS + _lib.DEVICE_SYMBOLS)
+
+
+def test_host_library_exports_host_symbols():
+    lib = C.CDLL(build.build_host())
+    for s in _lib.HOST_SYMBOLS:
+        assert hasattr(lib, s), s
+
+
+def test_hip_library_exports_every_symbol():
+    if not os.path.exists(build.HIP_SO):
+        pytest.skip("libtsgo_hip.so not built yet (run __graft_entry__.build())")
+    lib = C.CDLL(build.HIP_SO)
+    for s in declared_symbols():
+        assert hasattr(lib, s), s
+
+
+def test_device_entry_points_fail_loudly_without_a_gpu():
+    import torch
+    if torch.cuda.is_available() or not os.path.exists(build.HIP_SO):
+        pytest.skip("only meaningful on a CPU-only box with the library built")
+    lib = _lib.hip_lib()
+    h = C.c_void_p()
+    rc = lib.tsgo_create(None, C.byref(h))
+    assert rc != 0 and not h.value
+    assert b"no CPU fallback" in lib.tsgo_last_error()
+
+
+def test_product_never_imports_the_oracle():
+    bad = []
+    for root, _d, files in os.walk(os.path.join(ROOT, "toyslam_amd")):
+        for f in files:
+            if f.endswith((".py", ".h", ".cpp", ".hip")):
+                s = open(os.path.join(root, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", s, flags=re.M) or "oracle/" in s and f.endswith((".cpp", ".hip", ".h")) and "#include" in s and re.search(r'#include\s+"[^"]*oracle', s):
+                    bad.append(f)
+    assert not bad, bad

@@ -1,0 +1,135 @@
+"""Host layout builder + shard planner (product code, csrc/host/problem.cpp) and the sparse CPU twin
+(oracle/oracle_sparse.cpp) against the dense restatement."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import util
+from toyslam_amd import _lib, synth
+
+
+def probe(g, rank=0, world=1, gp=0, gl=0):
+    lib = _lib.host_lib()
+    info = _lib.tsgo_layout_info()
+    cg = g.c_struct()
+    _lib.check(lib, lib.tsgo_layout_probe(C.byref(cg), rank, world, gp, gl, C.byref(info)), "tsgo_layout_probe")
+    return info
+
+
+def test_layout_counts_c1():
+    g = util.c1_arrays()
+    i = probe(g)
+    assert (i.n_pose, i.n_lm_local, i.n_lm_total, i.n_lm_edges_local) == (150, 342, 342, 1974)
+    assert i.n_odom_slots == 2 * 149                          # every ODOM edge is listed at both ends
+    assert i.rows_by_pose * 64 >= 1974 and i.rows_by_lm * 64 >= 1974
+    assert i.lanes_per_pose in (1, 2, 4, 8) and i.lanes_per_lm in (1, 2, 4, 8)
+
+
+def test_padding_stays_moderate_on_synthetic_graphs():
+    g = synth.make(5000, 10, seed=1)
+    i = probe(g)
+    n_lm_edges = int((g.e_type == 1).sum())
+    assert i.rows_by_pose * 64 < 1.2 * n_lm_edges
+    assert i.rows_by_lm * 64 < 1.6 * n_lm_edges              # degree-sorted windows keep landmark padding low
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_shards_partition_landmarks_edges_and_poses(world):
+    g = synth.make(3000, 10, seed=2)
+    infos = [probe(g, r, world) for r in range(world)]
+    assert infos[0].lm_first == 0 and infos[-1].lm_last == g.n_landmarks
+    assert infos[0].pose_first == 0 and infos[-1].pose_last == g.n_poses
+    for a, b in zip(infos, infos[1:]):
+        assert a.lm_last == b.lm_first and a.pose_last == b.pose_first
+    assert sum(i.n_lm_edges_local for i in infos) == int((g.e_type == 1).sum())
+    assert sum(i.n_odom_slots for i in infos) == 2 * int((g.e_type == 0).sum())
+    share = np.array([i.n_lm_edges_local for i in infos], float)
+    assert share.max() / share.mean() < 1.1                   # balanced by edge count
+
+
+def test_layout_rejects_inconsistent_graphs():
+    g = util.tiny_arrays("tiny_a")
+    bad = g.copy(); bad.v_id[1] = bad.v_id[0]
+    with pytest.raises(RuntimeError, match="duplicate"):
+        probe(bad)
+    bad = g.copy(); bad.fixed = np.array([77], np.uint32)
+    with pytest.raises(RuntimeError, match="fixed vertex"):
+        probe(bad)
+    bad = g.copy(); bad.e_meas[0] = 0                           # singular ODOM measurement
+    with pytest.raises(RuntimeError, match="singular"):
+        probe(bad)
+
+
+def test_twin_one_step_equals_dense_solve_c1():
+    g = util.c1_arrays()
+    d_ref, err, _, _ = util.dense_solution(g)
+    r = oracle.sparse_step(util.to_oracle(g), 1e-13)
+    assert abs(r["chi2"] - err) < 1e-12 * err
+    assert np.abs(r["delta"] - d_ref).max() < 1e-10 * np.abs(d_ref).max()
+
+
+@pytest.mark.parametrize("name", ["tiny_a", "tiny_b", "tiny_c"])
+def test_twin_full_run_equals_dense_on_tiny_graphs(name):
+    g = util.tiny_arrays(name)
+    ref = oracle.optimize(util.to_oracle(g), 20, mode="cpp", solver="qr")
+    r = oracle.sparse_optimize(util.to_oracle(g), 20, pcg_tol=1e-14)
+    assert r["stop"] == ref["stop"] and r["iters"] == ref["iters"]
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-10, atol=1e-13)
+    assert util.max_vertex_diff(r["v_pos"], ref["v_pos"], g.v_type) < 1e-9
+
+
+def test_twin_full_run_equals_dense_c1():
+    g = util.c1_arrays()
+    ref = oracle.optimize(util.to_oracle(g), 50, mode="cpp", solver="chol")
+    r = oracle.sparse_optimize(util.to_oracle(g), 50, pcg_tol=1e-13)
+    assert r["stop"] == ref["stop"] == "plateau" and r["iters"] == ref["iters"]
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-10)
+    assert util.max_vertex_diff(r["v_pos"], ref["v_pos"], g.v_type) < 1e-9
+
+
+def test_twin_equals_dense_on_a_synthetic_graph_with_loop_closures():
+    g = synth.make(250, 8, loop_closures=20, seed=4)
+    d_ref, err, _, _ = util.dense_solution(g)
+    r = oracle.sparse_step(util.to_oracle(g), 1e-13)
+    assert abs(r["chi2"] - err) < 1e-12 * err
+    assert np.abs(r["delta"] - d_ref).max() < 1e-9 * np.abs(d_ref).max()
+
+
+def test_twin_against_scipy_sparse_direct_solve_at_2k_poses():
+    """Independent check at a size the dense path cannot reach: assemble H from the dense oracle's
+    per-edge (e, A, B) in scipy.sparse and solve directly."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    g = synth.make(2000, 10, seed=6)
+    o = util.to_oracle(g)
+    e, A, B = oracle.edge_eval(o)
+    dims = np.where(o.v_type == 0, 3, 2); off = np.concatenate([[0], np.cumsum(dims)[:-1]])
+    pos = {int(k): i for i, k in enumerate(o.v_id)}
+    n = int(dims.sum()); rows, cols, vals = [], [], []; b = np.zeros(n); chi = 0.0
+    for k in range(len(o.e_type)):
+        v1, v2 = pos[int(o.e_ids[k, 0])], pos[int(o.e_ids[k, 1])]
+        m = 3 if o.e_type[k] == 0 else 2
+        d1, d2 = dims[v1], dims[v2]
+        Ak = A[k, :m * d1].reshape(m, d1); Bk = B[k, :m * d2].reshape(m, d2); ek = e[k, :m]; w = o.e_inf[k, :m]
+        c2 = float((ek * ek * w).sum())
+        hw = 1.0 if c2 <= 2.25 else 1.5 / np.sqrt(c2)
+        chi += c2 if c2 <= 2.25 else 2 * np.sqrt(c2) * 1.5 - 2.25
+        W = np.diag(w * hw)
+        for (i0, X), (j0, Y) in [((off[v1], Ak), (off[v1], Ak)), ((off[v2], Bk), (off[v2], Bk)),
+                                 ((off[v1], Ak), (off[v2], Bk)), ((off[v2], Bk), (off[v1], Ak))]:
+            blk = X.T @ W @ Y
+            r_, c_ = np.meshgrid(np.arange(blk.shape[0]) + i0, np.arange(blk.shape[1]) + j0, indexing="ij")
+            rows.append(r_.ravel()); cols.append(c_.ravel()); vals.append(blk.ravel())
+        b[off[v1]:off[v1] + d1] -= Ak.T @ W @ ek; b[off[v2]:off[v2] + d2] -= Bk.T @ W @ ek
+    for f in o.fixed:
+        i0 = off[pos[int(f)]]
+        for k in range(dims[pos[int(f)]]):
+            rows.append([i0 + k]); cols.append([i0 + k]); vals.append([1e6])
+    H = sp.csc_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(n, n))
+    x = spl.spsolve(H, b)
+    r = oracle.sparse_step(o, 1e-13)
+    d = np.concatenate([r["delta"][i, :dims[i]] for i in range(len(dims))])
+    assert abs(r["chi2"] - chi) < 1e-10 * chi
+    assert np.abs(d - x).max() < 1e-8 * np.abs(x).max()

@@ -1,0 +1,186 @@
+// server.cpp — `graph_optimizer`: drop-in for ToySlam's remote optimizer process.
+//
+//   graph_optimizer [HOST=127.0.0.1] [PORT=8888] [ITERATIONS=10] [PIPELINE=cpu] [SOLVER=eigen]
+//                   [PRECISION=64] [PCG_TOL=1e-10] [DEVICE=0]
+//
+// Positional arguments 1-5 are the reference's (remote/app/main.cpp:12-16, README.md:15-18).  The
+// reference maps PIPELINE "cpu" -> CPU optimizer and anything else -> GPU, SOLVER "eigen" -> Eigen and
+// anything else -> CUDA, and then FORCES both by what the binary was built with (main.cpp:18-29).  This
+// binary is built with the HIP pipeline only, so — exactly like a reference build forces its enums —
+// every combination runs the HIP Gauss-Newton pipeline with the implicit-Schur PCG solver, and says
+// so in the banner.  There is no CPU path in this program.
+//
+// Protocol (remote/app/ConnectionHandlerGraph.h:20-52, remote/conn/ConnectionHandlerBase.h:45-128):
+//   request  = [i32 size][size bytes], reply = [u32 size][size bytes]; the connection is persistent
+//   (ConnectionHandler.h:30-32), many graphs per connection, any number of connections.  Transport is
+//   POSIX sockets (the reference uses Boost.Asio, which is not in this image); one thread per
+//   connection, requests serialised on the single device handle (the reference is single-threaded).
+#include <arpa/inet.h>
+#include <netdb.h>
+#include <netinet/in.h>
+#include <netinet/tcp.h>
+#include <signal.h>
+#include <sys/socket.h>
+#include <unistd.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../../include/tsgo.h"
+
+namespace {
+
+struct BlockTimer {    // same output shape as remote/tools/BlockTimer.cpp:6-18
+    std::string caption; unsigned level; std::chrono::steady_clock::time_point t0;
+    BlockTimer(const std::string& c, unsigned l = 0) : caption(c), level(l), t0(std::chrono::steady_clock::now()) {}
+    ~BlockTimer() {
+        const auto ms = std::chrono::duration_cast<std::chrono::milliseconds>(std::chrono::steady_clock::now() - t0).count();
+        std::cout << std::string(level, ' ') << "[" << caption << "] time: " << ms << "ms" << std::endl;
+    }
+};
+
+bool read_exact(int fd, void* buf, size_t n) {
+    char* p = (char*)buf;
+    while (n) {
+        const ssize_t r = ::recv(fd, p, n, 0);
+        if (r == 0) return false;
+        if (r < 0) { if (errno == EINTR) continue; std::cerr << "ReadAsync() error: " << std::strerror(errno) << std::endl; return false; }
+        p += r; n -= (size_t)r;
+    }
+    return true;
+}
+bool write_all(int fd, const void* buf, size_t n) {
+    const char* p = (const char*)buf;
+    while (n) {
+        const ssize_t r = ::send(fd, p, n, MSG_NOSIGNAL);
+        if (r < 0) { if (errno == EINTR) continue; std::cerr << "SendSync() error: " << std::strerror(errno) << std::endl; return false; }
+        p += r; n -= (size_t)r;
+    }
+    return true;
+}
+
+struct Server {
+    tsgo_optimizer* opt = nullptr;
+    std::mutex device_mutex;
+    int iterations = 10;
+
+    // one request: remote/app/ConnectionHandler.h:14-34
+    bool handle(int fd, std::vector<uint8_t>& payload) {
+        BlockTimer total{"Total"};
+        tsgo_wire_graph* w = nullptr;
+        {
+            BlockTimer t{"DeserializeGraph"};
+            if (tsgo_wire_decode(payload.data(), payload.size(), &w)) { std::cerr << tsgo_last_error() << std::endl; return false; }
+        }
+        tsgo_graph view; tsgo_wire_view(w, &view);
+        std::vector<double> v_pos((size_t)view.n_vertices * 3);
+        std::vector<uint8_t> reply;
+        bool ok = true;
+        {
+            std::lock_guard<std::mutex> lock(device_mutex);
+            BlockTimer t{"OptimizeHIP"};
+            tsgo_stats st;
+            if (tsgo_set_graph(opt, &view) || tsgo_optimize(opt, iterations, &st) || tsgo_get_vertices(opt, v_pos.data())) {
+                std::cerr << tsgo_last_error() << std::endl; ok = false;
+            } else {
+                if (st.stop_reason == TSGO_STOP_WORSE) std::cout << "Error is getting worse\n";       // OptimizerCpu.h:146
+                if (st.stop_reason == TSGO_STOP_PLATEAU) std::cout << "Plateau: NO MORE OPT\n";       // :169
+                if (st.stop_reason == TSGO_STOP_CONVERGED) std::cout << "CONVERGED\n";                // :175
+                const int last = st.iterations_run > 0 ? std::min(st.iterations_run, TSGO_MAX_TRACE) - 1 : 0;
+                std::cout << "Summary() error = " << st.chi2[last] << std::endl;                       // :182
+                std::cout << " [hip] iterations=" << st.iterations_run << " pcg_iters=" << st.pcg_iters_total
+                          << " setup=" << st.ms_setup << "ms linearize=" << st.ms_linearize << "ms solve=" << st.ms_solve
+                          << "ms update=" << st.ms_update << "ms" << std::endl;
+            }
+        }
+        if (ok) {
+            BlockTimer t{"SerializeGraph"};
+            const int64_t n = tsgo_wire_encode_response(w, v_pos.data(), nullptr, 0);
+            if (n < 0) { std::cerr << tsgo_last_error() << std::endl; ok = false; }
+            else { reply.resize((size_t)n); tsgo_wire_encode_response(w, v_pos.data(), reply.data(), reply.size()); }
+        }
+        tsgo_wire_free(w);
+        if (!ok) return false;
+        BlockTimer t{"Sending"};
+        std::cout << "SendSync() data size = " << reply.size() << std::endl;     // ConnectionHandlerBase.h:118
+        return write_all(fd, reply.data(), reply.size());
+    }
+
+    void connection(int fd) {
+        std::cout << "\n------ New Connection ------\n";                         // ConnectionHandler.h:10
+        int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
+        std::vector<uint8_t> payload;
+        for (;;) {
+            int32_t size = 0;                                                    // ConnectionHandlerGraph.h:37-43,57
+            if (!read_exact(fd, &size, sizeof(size))) break;
+            if (size <= 0) { std::cerr << "bad graph size " << size << std::endl; break; }
+            payload.resize((size_t)size);
+            if (!read_exact(fd, payload.data(), payload.size())) break;
+            if (!handle(fd, payload)) break;
+        }
+        ::close(fd);
+    }
+};
+
+}  // namespace
+
+int main(int argc, char* argv[]) {
+    signal(SIGPIPE, SIG_IGN);
+    std::cout << "HIP (gfx950) is supported\n";
+    try {
+        const std::string host = argc < 2 ? "127.0.0.1" : argv[1];
+        const std::string port = argc < 3 ? "8888" : argv[2];
+        const int iters = argc < 4 ? 10 : std::stoi(argv[3]);
+        const std::string targetS = argc < 5 ? "cpu" : argv[4];
+        const std::string solverS = argc < 6 ? "eigen" : argv[5];
+        const int precision = argc < 7 ? 64 : std::stoi(argv[6]);
+        const double tol = argc < 8 ? 1e-10 : std::stod(argv[7]);
+        const int device = argc < 9 ? 0 : std::stoi(argv[8]);
+        // the reference prints the enums after forcing them to what the build supports (main.cpp:21-34):
+        // 0 = EIGEN, 1 = CUDA; here both are always the accelerator pipeline.
+        std::cout << "iters: " << iters << ", optimizerType: 1, solverType: 1" << std::endl;
+        if (targetS == "cpu" || solverS == "eigen")
+            std::cout << "note: PIPELINE=" << targetS << " SOLVER=" << solverS
+                      << " requested; this build has the HIP pipeline only (gfx950, implicit-Schur PCG, f" << precision << ")\n";
+
+        tsgo_config cfg; tsgo_default_config(&cfg);
+        cfg.device = device; cfg.precision = precision; cfg.pcg_rel_tol = tol;
+        Server srv; srv.iterations = iters;
+        if (tsgo_create(&cfg, &srv.opt)) { std::cerr << "ConnectionManager error: " << tsgo_last_error() << std::endl; return 1; }
+
+        addrinfo hints{}; hints.ai_family = AF_UNSPEC; hints.ai_socktype = SOCK_STREAM; hints.ai_flags = AI_PASSIVE;
+        addrinfo* res = nullptr;
+        const int gai = getaddrinfo(host.c_str(), port.c_str(), &hints, &res);
+        if (gai != 0 || !res) { std::cerr << "ConnectionManager error: resolve: " << gai_strerror(gai) << std::endl; return 1; }
+        std::cout << "Endpoints:\n";                                             // ConnectionManagerServer.h:27-31
+        for (addrinfo* a = res; a; a = a->ai_next) {
+            char h[NI_MAXHOST], s[NI_MAXSERV];
+            if (!getnameinfo(a->ai_addr, a->ai_addrlen, h, sizeof(h), s, sizeof(s), NI_NUMERICHOST | NI_NUMERICSERV))
+                std::cout << " - " << h << ":" << s << std::endl;
+        }
+        const int lfd = ::socket(res->ai_family, res->ai_socktype, res->ai_protocol);   // first endpoint (:33)
+        if (lfd < 0) { std::cerr << "ConnectionManager error: socket: " << std::strerror(errno) << std::endl; return 1; }
+        int one = 1; setsockopt(lfd, SOL_SOCKET, SO_REUSEADDR, &one, sizeof(one));      // :35
+        if (::bind(lfd, res->ai_addr, res->ai_addrlen) || ::listen(lfd, 16)) {
+            std::cerr << "ConnectionManager error: bind/listen: " << std::strerror(errno) << std::endl; return 1;
+        }
+        freeaddrinfo(res);
+        std::cout << "listening" << std::endl;
+        for (;;) {                                                               // ConnectionManagerServer.h:46-61
+            const int fd = ::accept(lfd, nullptr, nullptr);
+            if (fd < 0) { if (errno == EINTR) continue; std::cerr << "accept: " << std::strerror(errno) << std::endl; break; }
+            std::thread([&srv, fd] { srv.connection(fd); }).detach();
+        }
+        tsgo_destroy(srv.opt);
+    } catch (std::exception& e) {
+        std::cerr << "ConnectionManager error: " << e.what() << std::endl;       // main.cpp:44-47
+    }
+    return 0;
+}

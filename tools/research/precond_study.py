@@ -210,5 +210,52 @@ def study2(n):
         M, nnz = multilevel2(S, xy, **kw)
         print(name, "nnz per level", nnz, pcg(S, b, M, tol=1e-8))
 
-if __name__ == "__main__" and len(sys.argv) > 2:
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "x":
     study2(int(sys.argv[1]))
+
+
+def multilevel3(S, xy, ms, smooth_levels, omega=0.7):
+    """like multilevel2 V(1,1) but prolongator smoothing only on the levels listed in smooth_levels"""
+    levels = []
+    A = S; pts = xy
+    for li, m in enumerate(ms):
+        P = A.shape[0] // 3
+        Z = rigid_Z(P, pts, m)
+        if li in smooth_levels:
+            D = A.tobsr((3, 3)); D.sort_indices()
+            dinv = np.zeros((P, 3, 3))
+            for i in range(P):
+                for k in range(D.indptr[i], D.indptr[i + 1]):
+                    if D.indices[k] == i: dinv[i] = np.linalg.inv(D.data[k])
+            Dinv = sp.bsr_matrix((dinv, np.arange(P), np.arange(P + 1)), shape=A.shape).tocsr()
+            Z = (Z - omega * (Dinv @ (A @ Z))).tocsr()
+        levels.append((A, block_jacobi(A, 3), Z))
+        A = (Z.T @ A @ Z).tocsr()
+        nagg = A.shape[0] // 3
+        pts = np.array([pts[a * m:min(P, (a + 1) * m)].mean(0) for a in range(nagg)])
+    lu = spl.splu(A.tocsc())
+    nnz = [l[0].nnz for l in levels] + [A.nnz]
+    def cycle(l, r):
+        if l == len(levels): return lu.solve(r)
+        A, sm, Z = levels[l]
+        z = sm.matvec(r)
+        z = z + Z @ cycle(l + 1, Z.T @ (r - A @ z))
+        z = z + sm.matvec(r - A @ z)
+        return z
+    return spl.LinearOperator(S.shape, matvec=lambda r: cycle(0, r)), nnz
+
+
+def study3(n):
+    g = synth.make(n, 10)
+    S, b = assemble(g); xy = g.v_pos[:g.n_poses, :2]
+    for name, ms, sl in [("unsmoothed L0 (m=4), SA above 8,8,8", (4, 8, 8, 8), {1, 2, 3}),
+                         ("unsmoothed L0 (m=8), SA above 8,8", (8, 8, 8), {1, 2}),
+                         ("unsmoothed L0 (m=2), SA above 8,8,8", (2, 8, 8, 8), {1, 2, 3}),
+                         ("SA all 8,8,8", (8, 8, 8), {0, 1, 2}),
+                         ("SA all 16,8,8", (16, 8, 8), {0, 1, 2}),
+                         ("SA all 8,8,8 omega .5", (8, 8, 8), {0, 1, 2})]:
+        M, nnz = multilevel3(S, xy, ms, sl, omega=0.5 if "omega" in name else 0.7)
+        print(name, nnz, pcg(S, b, M, tol=1e-8), flush=True)
+
+if __name__ == "__main__" and len(sys.argv) > 2 and sys.argv[2] == "3":
+    study3(int(sys.argv[1]))

@@ -59,6 +59,8 @@ typedef struct tsgo_config {
     int32_t use_graphs;      /* 1 (default): replay the PCG iteration from a hipGraph */
     int32_t rank, world;     /* edge sharding: this process owns shard `rank` of `world` (default 0, 1) */
     int32_t verbose;
+    int32_t preconditioner;  /* 1 (default, single shard): smoothed-aggregation multigrid V-cycle on the reduced
+                                pose system; 0: block-Jacobi on its 3x3 diagonal (always used when world > 1) */
 } tsgo_config;
 
 enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_CONVERGED = 3, TSGO_STOP_SOLVER = 4 };
@@ -115,7 +117,8 @@ int tsgo_comm_init(tsgo_optimizer* opt, const uint8_t id[128]);
 
 /* Timing probe used by bench.py: average device time (hipEvent, microseconds) of `reps` back-to-back
  * launches of one kernel on the handle's stream, and the algorithmic bytes one launch moves.
- * which: 0 schur_lm, 1 schur_pose, 2 cg_update, 3 lin_lm, 4 lin_pose, 5 one whole PCG iteration. */
+ * which: 0 schur_lm, 1 schur_pose, 2 cg_update, 3 lin_lm, 4 lin_pose, 5 one whole PCG iteration
+ * (preconditioner application included), 6 the multigrid numeric setup of one GN iteration. */
 int tsgo_time_kernel(tsgo_optimizer* opt, int32_t which, int32_t reps, double* us_per_launch, double* bytes_per_launch);
 
 const char* tsgo_last_error(void);

@@ -52,9 +52,9 @@ def lib():
         L.oracle_solve_f64.argtypes = [f64p, f64p, C.c_int, C.c_int]
         L.oracle_update_pose_f64.argtypes = [f64p, f64p]
         L.oracle_num_unknowns.argtypes = [C.c_int, u32p]
-        L.oracle_sparse_step.argtypes = _GRAPH + [C.c_double, C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p,
+        L.oracle_sparse_step.argtypes = _GRAPH + [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p,
                                                   f64p, f64p, i32p]
-        L.oracle_sparse_optimize.argtypes = _GRAPH + [f64p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int,
+        L.oracle_sparse_optimize.argtypes = _GRAPH + [f64p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                                       ALLREDUCE_FN, C.c_void_p, f64p, i32p, i32p, i32p, f64p,
                                                       f64p, f64p]
         L.oracle_set_threads.argtypes = [C.c_int]
@@ -166,22 +166,25 @@ def _hook(allreduce):
     return ALLREDUCE_FN(cb)
 
 
-def sparse_step(g, pcg_tol=1e-12, max_cg=100000, rank=0, world=1, allreduce=None):
+PRECOND = {"jacobi": 0, "amg": 1}
+
+
+def sparse_step(g, pcg_tol=1e-12, max_cg=100000, rank=0, world=1, allreduce=None, precond="jacobi"):
     """One GN step by the sparse CPU twin (implicit-Schur PCG): dict(delta, chi2, cg_iters)."""
     d = np.zeros((len(g.v_id), 3)); chi = np.zeros(1); it = np.zeros(1, np.int32)
     h = _hook(allreduce)
-    rc = lib().oracle_sparse_step(*g.args(), pcg_tol, max_cg, rank, world, h, None, d, chi, it)
+    rc = lib().oracle_sparse_step(*g.args(), pcg_tol, max_cg, PRECOND[precond], rank, world, h, None, d, chi, it)
     if rc:
         raise RuntimeError("oracle_sparse_step rc=%d" % rc)
     return dict(delta=d, chi2=float(chi[0]), cg_iters=int(it[0]))
 
 
-def sparse_optimize(g, iterations, pcg_tol=1e-12, max_cg=100000, rank=0, world=1, allreduce=None):
+def sparse_optimize(g, iterations, pcg_tol=1e-12, max_cg=100000, rank=0, world=1, allreduce=None, precond="jacobi"):
     """Full GN loop by the sparse CPU twin with the reference's stop rules."""
     out = np.zeros_like(g.v_pos); chi2 = np.zeros(max(iterations, 1)); cg = np.zeros(max(iterations, 1), np.int32)
     ir = np.zeros(1, np.int32); sr = np.zeros(1, np.int32); dn = np.zeros(1); tl = np.zeros(1); ts = np.zeros(1)
     h = _hook(allreduce)
-    rc = lib().oracle_sparse_optimize(*g.args(), out, iterations, pcg_tol, max_cg, rank, world, h, None, chi2, ir, sr,
+    rc = lib().oracle_sparse_optimize(*g.args(), out, iterations, pcg_tol, max_cg, PRECOND[precond], rank, world, h, None, chi2, ir, sr,
                                       cg, dn, tl, ts)
     if rc:
         raise RuntimeError("oracle_sparse_optimize rc=%d" % rc)

@@ -22,6 +22,8 @@
 #include <string>
 #include <vector>
 
+#include "amg_twin.h"
+#include "host/amg.h"
 #include "host/problem.h"
 #include "tsgo_math.h"
 
@@ -42,6 +44,10 @@ struct Twin {
     std::vector<double> dp, minv, r, z, p, q, x, s; // per pose
     double chi2 = 0;
     std::vector<double> gscratch;
+    bool use_amg = false;
+    tsgo::AmgSym amg;
+    amgtwin::Hierarchy hier;
+    std::vector<double> res0, s0;
 
     void allreduce(double* b, int64_t n) { if (hook && pr.world > 1) hook(b, n, hook_ctx); }
 
@@ -62,6 +68,80 @@ struct Twin {
         dp.assign((size_t)P * 6, 0); minv.assign((size_t)P * 6, 0);
         for (auto* v : {&r, &z, &p, &q, &x, &s}) v->assign((size_t)P * 3, 0);
         return std::string();
+    }
+
+    std::string enable_amg() {
+        std::string e = tsgo::build_amg(pr, amg);
+        if (!e.empty()) return e;
+        hier.alloc(amg);
+        res0.assign((size_t)P * 3, 0); s0.assign((size_t)P * 3, 0);
+        use_amg = true;
+        return std::string();
+    }
+
+    // level 0 of the hierarchy: explicit Schur complement blocks (twin of k_schur_blocks)
+    void build_schur_blocks() {
+        const tsgo::AmgLevel& L = amg.levels[0];
+        std::vector<double>& A = hier.A[0];
+        const tsgo::SellTable& tb = pr.by_pose; const size_t S = tb.slots();
+        const size_t SO = pr.odom.slots();
+        #pragma omp parallel for schedule(static)
+        for (int i = 0; i < P; ++i) {
+            const double ci = ps[4 * (size_t)i + 2], si = ps[4 * (size_t)i + 3];
+            for (int b = L.A.ptr[i]; b < L.A.ptr[i + 1]; ++b) {
+                const int k = L.A.col[b];
+                double* o = &A[(size_t)b * 9];
+                if (k == i) {
+                    const double* o18 = &part[(size_t)i * 18];
+                    const double m[6] = {o18[0] - o18[9], o18[1] - o18[10], o18[2] - o18[11], o18[3] - o18[12], o18[4] - o18[13], o18[5] - o18[14]};
+                    o[0] = m[0]; o[1] = m[1]; o[2] = m[2]; o[3] = m[1]; o[4] = m[3]; o[5] = m[4]; o[6] = m[2]; o[7] = m[4]; o[8] = m[5];
+                    continue;
+                }
+                const double ck = ps[4 * (size_t)k + 2], sk = ps[4 * (size_t)k + 3];
+                double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+                for (int q = amg.schur.ptr[b]; q < amg.schur.ptr[b + 1]; ++q) {
+                    const size_t e1 = amg.schur.slot_i[q], e2 = amg.schur.slot_k[q];
+                    const uint32_t l = tb.idx[e1];
+                    const double a0i = pa[e1], a1i = pa[S + e1], vi0 = pa[3 * S + e1], vi1 = -pa[2 * S + e1];
+                    const double a0k = pa[e2], a1k = pa[S + e2], vk0 = pa[3 * S + e2], vk1 = -pa[2 * S + e2];
+                    const double nxx = dlinv[3 * (size_t)l], nxy = dlinv[3 * (size_t)l + 1], nyy = dlinv[3 * (size_t)l + 2];
+                    // G = Ri^T N Rk
+                    const double m00 = nxx * ck + nxy * sk, m01 = -nxx * sk + nxy * ck, m10 = nxy * ck + nyy * sk, m11 = -nxy * sk + nyy * ck;
+                    const double g00 = ci * m00 + si * m10, g01 = ci * m01 + si * m11, g10 = -si * m00 + ci * m10, g11 = -si * m01 + ci * m11;
+                    const double q00 = a0i * g00 * a0k, q01 = a0i * g01 * a1k, q10 = a1i * g10 * a0k, q11 = a1i * g11 * a1k;
+                    // Ri Q Rk^T
+                    const double u00 = ci * q00 - si * q10, u01 = ci * q01 - si * q11, u10 = si * q00 + ci * q10, u11 = si * q01 + ci * q11;   // Ri Q
+                    acc[0] += u00 * ck - u01 * sk; acc[1] += u00 * sk + u01 * ck; acc[3] += u10 * ck - u11 * sk; acc[4] += u10 * sk + u11 * ck;
+                    const double qv0 = q00 * vk0 + q01 * vk1, qv1 = q10 * vk0 + q11 * vk1;      // Q vk
+                    acc[2] -= ci * qv0 - si * qv1; acc[5] -= si * qv0 + ci * qv1;
+                    const double vq0 = vi0 * q00 + vi1 * q10, vq1 = vi0 * q01 + vi1 * q11;      // vi^T Q
+                    acc[6] -= vq0 * ck - vq1 * sk; acc[7] -= vq0 * sk + vq1 * ck;
+                    acc[8] += vi0 * qv0 + vi1 * qv1;
+                }
+                for (int m = 0; m < 9; ++m) o[m] = -acc[m];
+                for (int q = amg.schur.od_ptr[b]; q < amg.schur.od_ptr[b + 1]; ++q) {
+                    const size_t e = amg.schur.od_slot[q];
+                    o[0] -= oa[e]; o[4] -= oa[SO + e]; o[8] -= oa[2 * SO + e];
+                }
+            }
+        }
+    }
+
+    // z = M^-1 r by one V(1,1) cycle (level 0 uses the implicit Schur product)
+    void amg_apply() {
+        for (int i = 0; i < P; ++i) tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
+        if (amg.levels.empty()) return;
+        schur_lm(z); schur_pose(z, s0);
+        for (size_t k = 0; k < s0.size(); ++k) res0[k] = r[k] - s0[k];
+        hier.restrict_to(0, res0, hier.r[1]);
+        hier.cycle(1);
+        hier.prolong_add(0, hier.z[1], z);
+        schur_lm(z); schur_pose(z, s0);
+        for (int i = 0; i < P; ++i) {
+            double d0, d1, d2;
+            tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i] - s0[3 * (size_t)i], r[3 * (size_t)i + 1] - s0[3 * (size_t)i + 1], r[3 * (size_t)i + 2] - s0[3 * (size_t)i + 2], d0, d1, d2);
+            z[3 * (size_t)i] += d0; z[3 * (size_t)i + 1] += d1; z[3 * (size_t)i + 2] += d2;
+        }
     }
 
     template <typename F> static void for_slots(const tsgo::SellTable& tb, int v, F f) {
@@ -241,7 +321,15 @@ struct Twin {
         // gauge of owned poses goes into the partial so that it is summed exactly once across shards
         for (int i = pr.pose_first; i < pr.pose_last; ++i) { part[(size_t)i * 18] += pr.gauge_p[i]; part[(size_t)i * 18 + 3] += pr.gauge_p[i]; part[(size_t)i * 18 + 5] += pr.gauge_p[i]; }
         allreduce(part.data(), (int64_t)part.size());
-        return finalize();
+        const double g0 = finalize();
+        if (use_amg) {
+            if (!amg.levels.empty()) { build_schur_blocks(); hier.setup_from_level0(); }
+            amg_apply();
+            double g = 0;
+            for (int i = 0; i < 3 * P; ++i) g += r[i] * z[i];
+            return g;
+        }
+        return g0;
     }
 
     // Chronopoulos-Gear PCG on the reduced (pose) system S x = b~.  Returns iterations.
@@ -269,8 +357,12 @@ struct Twin {
                     p[j] = z[j] + beta * p[j]; q[j] = buf[j] + beta * q[j];
                     x[j] += alpha * p[j]; r[j] -= alpha * q[j];
                 }
-                tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
-                for (int k = 0; k < 3; ++k) gi[i] += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
+                if (!use_amg) tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
+                if (!use_amg) for (int k = 0; k < 3; ++k) gi[i] += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
+            }
+            if (use_amg) {
+                amg_apply();
+                for (int i = 0; i < P; ++i) for (int k = 0; k < 3; ++k) gi[i] += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
             }
             double gnew = 0;
             for (int i = 0; i < P; ++i) gnew += gi[i];       // serial: identical on every shard
@@ -339,11 +431,12 @@ void oracle_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
 
 // One Gauss-Newton step at the given state: delta (3 per vertex, graph order; landmarks of other
 // shards are left 0), chi2, PCG iterations.  hook/ctx: all-reduce(sum) over shards, may be NULL.
-int oracle_sparse_step(GRAPH_ARGS, double pcg_tol, int max_cg, int rank, int world, allreduce_fn hook, void* ctx,
+int oracle_sparse_step(GRAPH_ARGS, double pcg_tol, int max_cg, int precond, int rank, int world, allreduce_fn hook, void* ctx,
                        double* delta_out, double* chi2_out, int* cg_iters) {
     Twin tw; tw.hook = hook; tw.hook_ctx = ctx;
     const tsgo_graph g = make_view(GRAPH_PASS);
     if (!tw.init(g, rank, world).empty()) return -2;
+    if (precond == 1 && !tw.enable_amg().empty()) return -5;
     const double gamma0 = tw.linearize();
     bool ok; *cg_iters = tw.solve(gamma0, pcg_tol, max_cg, &ok);
     std::vector<double> dl; tw.backsub(dl);
@@ -355,12 +448,13 @@ int oracle_sparse_step(GRAPH_ARGS, double pcg_tol, int max_cg, int rank, int wor
 
 // Full loop with the reference's rules (OptimizerCpu.h:80-180).  v_pos_out: 3 per vertex (landmarks of
 // other shards are left at their input value).  stop_reason as in oracle_dense.cpp.
-int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double pcg_tol, int max_cg, int rank, int world,
+int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double pcg_tol, int max_cg, int precond, int rank, int world,
                            allreduce_fn hook, void* ctx, double* chi2_trace, int* iters_run, int* stop_reason,
                            int* cg_trace, double* last_delta_norm, double* seconds_lin, double* seconds_solve) {
     Twin tw; tw.hook = hook; tw.hook_ctx = ctx;
     const tsgo_graph g = make_view(GRAPH_PASS);
     if (!tw.init(g, rank, world).empty()) return -2;
+    if (precond == 1 && !tw.enable_amg().empty()) return -5;
     std::memcpy(v_pos_out, v_pos, sizeof(double) * 3 * (size_t)nV);
     double prevErr = -1; int penalty = 0;
     *stop_reason = 0; *iters_run = 0; *last_delta_norm = 0;

@@ -13,9 +13,11 @@ from toyslam_amd.optimizer import HipOptimizer
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(scope="module")
-def opt():
-    o = HipOptimizer(pcg_rel_tol=1e-12)
+@pytest.fixture(scope="module", params=["amg", "jacobi"])
+def opt(request):
+    """Both preconditioners go through every parity check: the multigrid V-cycle (default) and the
+    block-Jacobi fallback (the one edge-sharded runs use)."""
+    o = HipOptimizer(pcg_rel_tol=1e-12, preconditioner=request.param)
     yield o
     o.close()
 
@@ -86,11 +88,12 @@ def test_lanes_per_vertex_variants_agree_with_dense(lanes):
     assert np.abs(r["delta"] - d_ref).max() <= 1e-8 * np.abs(d_ref).max()
 
 
-def test_hipgraph_replay_equals_eager_launches():
+@pytest.mark.parametrize("precond", ["amg", "jacobi"])
+def test_hipgraph_replay_equals_eager_launches(precond):
     g = synth.make(2000, 10, seed=5)
     res = []
     for use_graphs in (True, False):
-        o = HipOptimizer(pcg_rel_tol=1e-10, use_graphs=use_graphs)
+        o = HipOptimizer(pcg_rel_tol=1e-10, use_graphs=use_graphs, preconditioner=precond)
         try:
             o.set_graph(g)
             r = o.optimize(3)
@@ -102,11 +105,13 @@ def test_hipgraph_replay_equals_eager_launches():
     np.testing.assert_array_equal(res[0][1], res[1][1])
 
 
-def test_c2_10k_poses_against_sparse_cpu_twin():
-    """BASELINE config 2 (10k poses / 100k LM edges): 5 GN iterations, GPU vs the CPU twin."""
+@pytest.mark.parametrize("precond", ["amg", "jacobi"])
+def test_c2_10k_poses_against_sparse_cpu_twin(precond):
+    """BASELINE config 2 (10k poses / 100k LM edges): 5 GN iterations, GPU vs the CPU twin (which runs the
+    OTHER preconditioner, so the two solves share nothing but the mathematics)."""
     g = synth.make_config("c2_10k")
-    ref = oracle.sparse_optimize(util.to_oracle(g), 5, pcg_tol=1e-12)
-    o = HipOptimizer(pcg_rel_tol=1e-12)
+    ref = oracle.sparse_optimize(util.to_oracle(g), 5, pcg_tol=1e-12, precond="jacobi" if precond == "amg" else "amg")
+    o = HipOptimizer(pcg_rel_tol=1e-12, preconditioner=precond)
     try:
         o.set_graph(g)
         r = o.optimize(5)
@@ -116,6 +121,30 @@ def test_c2_10k_poses_against_sparse_cpu_twin():
     np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)             # north_star: 1e-6
     assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-7             # north_star: 1e-6
     assert np.all(np.diff(r["chi2"]) < 0)
+    if precond == "amg":
+        assert r["cg_iters"].max() < 120, r["cg_iters"]                       # block-Jacobi needs ~2 800 here
+
+
+def test_bench_tolerance_meets_the_north_star_bar():
+    """bench.py runs PCG at rel tol 1e-8: final chi^2 (relative) and poses (absolute) stay within 1e-6 of
+    the dense cpu/eigen restatement on config 1 and of the tightly converged twin on config 2."""
+    g = util.c1_arrays()
+    ref = oracle.optimize(util.to_oracle(g), 50, mode="cpp", solver="chol")
+    o = HipOptimizer(pcg_rel_tol=1e-8)
+    try:
+        o.set_graph(g)
+        r = o.optimize(50)
+        assert r["iters"] == ref["iters"] and r["stop"] == ref["stop"]
+        assert abs(r["chi2"][-1] - ref["chi2"][-1]) <= 1e-6 * ref["chi2"][-1]
+        assert util.max_vertex_diff(o.vertices(), ref["v_pos"], g.v_type) < 1e-6
+        g2 = synth.make_config("c2_10k")
+        ref2 = oracle.sparse_optimize(util.to_oracle(g2), 10, pcg_tol=1e-12, precond="amg")
+        o.set_graph(g2)
+        r2 = o.optimize(10)
+        assert abs(r2["chi2"][-1] - ref2["chi2"][-1]) <= 1e-6 * ref2["chi2"][-1]
+        assert util.max_vertex_diff(o.vertices(), ref2["v_pos"], g2.v_type) < 1e-6
+    finally:
+        o.close()
 
 
 def test_f32_mode_tracks_f64_loosely():
@@ -157,6 +186,7 @@ def test_c3_full_size_properties():
     finally:
         o.close()
     assert r["iters"] == 3 and np.all(np.diff(r["chi2"]) < 0)
+    assert r["cg_iters"].max() < 200, r["cg_iters"]        # multigrid keeps the solve at tens of iterations
     # (2) damped GN contracts chi^2 by roughly (1-0.2)^2 per step far from the optimum
     ratio = r["chi2"][1:] / r["chi2"][:-1]
     assert np.all(ratio < 0.9) and np.all(ratio > 0.4)

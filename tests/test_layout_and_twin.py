@@ -133,3 +133,25 @@ def test_twin_against_scipy_sparse_direct_solve_at_2k_poses():
     d = np.concatenate([r["delta"][i, :dims[i]] for i in range(len(dims))])
     assert abs(r["chi2"] - chi) < 1e-10 * chi
     assert np.abs(d - x).max() < 1e-8 * np.abs(x).max()
+
+
+@pytest.mark.parametrize("n_poses", [40, 300, 3000])
+def test_twin_multigrid_preconditioner_gives_the_same_solution_in_far_fewer_iterations(n_poses):
+    g = synth.make(n_poses, 10, loop_closures=10, seed=8)
+    o = util.to_oracle(g)
+    a = oracle.sparse_step(o, 1e-12, precond="jacobi")
+    b = oracle.sparse_step(o, 1e-12, precond="amg")
+    assert abs(a["chi2"] - b["chi2"]) <= 1e-13 * a["chi2"]
+    assert np.abs(a["delta"] - b["delta"]).max() <= 1e-8 * np.abs(a["delta"]).max()
+    if n_poses >= 300:
+        assert b["cg_iters"] * 5 < a["cg_iters"]
+
+
+def test_twin_multigrid_full_run_c1_matches_dense():
+    g = util.c1_arrays()
+    ref = oracle.optimize(util.to_oracle(g), 50, mode="cpp", solver="chol")
+    r = oracle.sparse_optimize(util.to_oracle(g), 50, pcg_tol=1e-13, precond="amg")
+    assert r["stop"] == ref["stop"] and r["iters"] == ref["iters"]
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-10)
+    assert util.max_vertex_diff(r["v_pos"], ref["v_pos"], g.v_type) < 1e-9
+    assert r["cg_iters"].max() < 30

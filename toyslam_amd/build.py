@@ -5,7 +5,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-HOST_SRC = ["host/problem.cpp", "host/codec.cpp", "host/synth.cpp", "host/host_api.cpp", "host/errors.cpp"]
+HOST_SRC = ["host/problem.cpp", "host/amg.cpp", "host/codec.cpp", "host/synth.cpp", "host/host_api.cpp", "host/errors.cpp"]
 HIP_SO = os.path.join(HERE, "libtsgo_hip.so")
 HOST_SO = os.path.join(HERE, "libtsgo_host.so")
 SERVER = os.path.join(HERE, "graph_optimizer")

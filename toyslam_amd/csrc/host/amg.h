@@ -1,0 +1,71 @@
+// amg.h — symbolic (pattern) side of the smoothed-aggregation multigrid preconditioner for the
+// reduced pose system S (built once per request on the host; all numeric work is on the device).
+//
+// Why: the reference solves H delta = b with a dense QR (remote/solver/SolverEigen.h:20).  The sparse
+// replacement is PCG on S = Hpp - W Dl^-1 W^T; with a block-Jacobi preconditioner a 100k-pose graph
+// needs ~6 000 iterations per Gauss-Newton step (profiles/r01a_*).  Pose graphs are long chains with
+// sparse loop closures: their slow modes are rigid motions of trajectory pieces.  A V(1,1) cycle over
+// aggregates of 8 consecutive poses whose coarse spaces are the three rigid modes (tx, ty, rotation
+// about the aggregate's centroid), with a Jacobi-smoothed prolongator, brings that to ~50.
+//
+// Level l holds A_l (block CSR, 3x3 blocks; level 0 = explicit Schur complement), aggregates, the
+// prolongator P_l = (I - w D^-1 A_l) Z_l and the Galerkin product A_{l+1} = P_l^T (A_l P_l).  Every
+// numeric product is a gather over precomputed (x, y) block-pair lists: no atomics, fixed order.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "problem.h"
+
+namespace tsgo {
+
+constexpr int kAggSize = 8;          // nodes per aggregate
+constexpr int kCoarsestMax = 28;     // stop coarsening at <= this many block rows (dense inverse in LDS, <= 84 x 84)
+constexpr double kProlongOmega = 0.7;
+
+struct BlockCsr {
+    int n_rows = 0, n_cols = 0;
+    std::vector<int> ptr, col;
+    int nnz() const { return (int)col.size(); }
+};
+
+struct PairList {                    // output block o sums over pairs [ptr[o], ptr[o+1])
+    std::vector<int> ptr, x, y;
+};
+
+struct AmgLevel {
+    int n = 0, n_agg = 0;
+    BlockCsr A;                      // pattern of A_l
+    std::vector<int> diag;           // per row: index of its diagonal block
+    std::vector<int> agg;            // node -> aggregate
+    std::vector<double> rel;         // 2 per node: position relative to the aggregate centroid
+    BlockCsr P;                      // n x n_agg
+    std::vector<int> p_self;         // per P block: 1 when col == agg(row)
+    PairList p_src;                  // per P block (i,a): x = A block (i,k) with agg(k) == a, y = k
+    BlockCsr R;                      // n_agg x n (pattern of P^T)
+    std::vector<int> r_to_p;         // per R block: the P block it transposes
+    BlockCsr T;                      // n x n_agg: pattern of A_l P_l
+    PairList t_src;                  // per T block: x = A block, y = P block
+    PairList a_src;                  // per A_{l+1} block: x = P block (transposed), y = T block
+};
+
+struct SchurLists {                  // level 0: how each off-diagonal S block is summed
+    std::vector<int> ptr;            // per S block
+    std::vector<uint32_t> slot_i, slot_k;   // by_pose slots of the two LM edges sharing a landmark
+    std::vector<int> od_ptr;         // per S block
+    std::vector<uint32_t> od_slot;   // odom-table slots (row i side) joining i and k
+};
+
+struct AmgSym {
+    std::vector<AmgLevel> levels;    // levels[l] coarsens A_l to A_{l+1}
+    BlockCsr A_last;                 // pattern of the coarsest matrix
+    std::vector<int> diag_last;
+    SchurLists schur;
+    std::vector<int> order;          // internal pose -> position along the trajectory used for aggregation
+};
+
+// Builds the hierarchy for a single-shard problem.  Returns "" or an error text.
+std::string build_amg(const Problem& pr, AmgSym& out);
+
+}  // namespace tsgo

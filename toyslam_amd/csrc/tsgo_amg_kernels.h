@@ -1,0 +1,325 @@
+// tsgo_amg_kernels.h — device side of the smoothed-aggregation multigrid preconditioner (host/amg.h):
+// numeric setup once per Gauss-Newton iteration, V(1,1) cycle once per PCG iteration.
+//
+// All blocks are 3x3 row-major.  Every sum is a gather over a precomputed list in fixed order: no
+// atomics, bitwise reproducible.  The coarse levels are tiny (12.5k / 1.5k / 196 / 25 block rows at
+// 100k poses): those kernels are latency-bound by design and kept deliberately simple; the bytes are
+// in level 0, whose residuals reuse the implicit Schur passes of tsgo_kernels.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tsgo_kernels.h"
+
+namespace tsgo {
+
+constexpr int kLpr = 8;                  // lanes cooperating on one block row in the block-CSR kernels
+constexpr int kDenseMax = 84;            // coarsest matrix is at most 84 x 84 (host/amg.h: kCoarsestMax * 3)
+
+template <typename T> __device__ __forceinline__ void m3_mul_acc(const T* a, const T* b, T* c) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[3 * i + j] += a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+}
+template <typename T> __device__ __forceinline__ void m3_tmul_acc(const T* a, const T* b, T* c) {   // c += a^T b
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) c[3 * i + j] += a[i] * b[j] + a[3 + i] * b[3 + j] + a[6 + i] * b[6 + j];
+}
+template <typename T> __device__ __forceinline__ void m3_inv(const T* m, T* o) {
+    const T c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
+    const T det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    if (!(fabs(det) > T(0))) { for (int k = 0; k < 9; ++k) o[k] = T(0); return; }
+    const T r = T(1) / det;
+    o[0] = c00 * r; o[1] = (m[2] * m[7] - m[1] * m[8]) * r; o[2] = (m[1] * m[5] - m[2] * m[4]) * r;
+    o[3] = c01 * r; o[4] = (m[0] * m[8] - m[2] * m[6]) * r; o[5] = (m[2] * m[3] - m[0] * m[5]) * r;
+    o[6] = c02 * r; o[7] = (m[1] * m[6] - m[0] * m[7]) * r; o[8] = (m[0] * m[4] - m[1] * m[3]) * r;
+}
+
+// ---- numeric setup ---------------------------------------------------------------------------------
+// Explicit Schur complement blocks S_ik (level 0 of the hierarchy), one thread per block.
+//   diagonal: Dp - Sd from the linearisation partials; off-diagonal: -sum_j W_ij N_j W_kj^T - odom.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
+                                                         const int* __restrict__ sptr, const uint32_t* __restrict__ slot_i,
+                                                         const uint32_t* __restrict__ slot_k, const int* __restrict__ optr,
+                                                         const uint32_t* __restrict__ oslot, Table<T> tb, const T* __restrict__ od_dyn,
+                                                         size_t od_slots, const T* __restrict__ lmrec, const T* __restrict__ ps,
+                                                         const T* __restrict__ part, T* __restrict__ A) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= nnz) return;
+    const int i = blk_row[b], k = blk_col[b];
+    T* o = A + (size_t)b * 9;
+    if (i == k) {
+        const T* p = part + (size_t)i * 18;
+        const T m0 = p[0] - p[9], m1 = p[1] - p[10], m2 = p[2] - p[11], m3 = p[3] - p[12], m4 = p[4] - p[13], m5 = p[5] - p[14];
+        o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m1; o[4] = m3; o[5] = m4; o[6] = m2; o[7] = m4; o[8] = m5;
+        return;
+    }
+    const T ci = ps[(size_t)i * 4 + 2], si = ps[(size_t)i * 4 + 3], ck = ps[(size_t)k * 4 + 2], sk = ps[(size_t)k * 4 + 3];
+    const size_t S = tb.slots;
+    T acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = sptr[b]; q < sptr[b + 1]; ++q) {
+        const size_t e1 = slot_i[q], e2 = slot_k[q];
+        const uint32_t l = tb.idx[e1];
+        const T a0i = tb.dyn[e1], a1i = tb.dyn[S + e1], vi0 = tb.dyn[3 * S + e1], vi1 = -tb.dyn[2 * S + e1];
+        const T a0k = tb.dyn[e2], a1k = tb.dyn[S + e2], vk0 = tb.dyn[3 * S + e2], vk1 = -tb.dyn[2 * S + e2];
+        const T* lr = lmrec + (size_t)l * kLmRec;
+        const T nxx = lr[2], nxy = lr[3], nyy = lr[4];
+        const T m00 = nxx * ck + nxy * sk, m01 = nxy * ck - nxx * sk, m10 = nxy * ck + nyy * sk, m11 = nyy * ck - nxy * sk;
+        const T g00 = ci * m00 + si * m10, g01 = ci * m01 + si * m11, g10 = ci * m10 - si * m00, g11 = ci * m11 - si * m01;
+        const T q00 = a0i * g00 * a0k, q01 = a0i * g01 * a1k, q10 = a1i * g10 * a0k, q11 = a1i * g11 * a1k;
+        const T u00 = ci * q00 - si * q10, u01 = ci * q01 - si * q11, u10 = si * q00 + ci * q10, u11 = si * q01 + ci * q11;
+        acc[0] += u00 * ck - u01 * sk; acc[1] += u00 * sk + u01 * ck; acc[3] += u10 * ck - u11 * sk; acc[4] += u10 * sk + u11 * ck;
+        const T qv0 = q00 * vk0 + q01 * vk1, qv1 = q10 * vk0 + q11 * vk1;
+        acc[2] -= ci * qv0 - si * qv1; acc[5] -= si * qv0 + ci * qv1;
+        const T vq0 = vi0 * q00 + vi1 * q10, vq1 = vi0 * q01 + vi1 * q11;
+        acc[6] -= vq0 * ck - vq1 * sk; acc[7] -= vq0 * sk + vq1 * ck;
+        acc[8] += vi0 * qv0 + vi1 * qv1;
+    }
+    T d0 = 0, d1 = 0, d2 = 0;
+    for (int q = optr[b]; q < optr[b + 1]; ++q) {
+        const size_t e = oslot[q];
+        d0 += od_dyn[e]; d1 += od_dyn[od_slots + e]; d2 += od_dyn[2 * od_slots + e];
+    }
+    o[0] = -acc[0] - d0; o[1] = -acc[1]; o[2] = -acc[2]; o[3] = -acc[3]; o[4] = -acc[4] - d1; o[5] = -acc[5];
+    o[6] = -acc[6]; o[7] = -acc[7]; o[8] = -acc[8] - d2;
+}
+
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_block_inv(int n, const int* __restrict__ diag, const T* __restrict__ A, T* __restrict__ Dinv) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    T m[9], o[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) m[k] = A[(size_t)diag[i] * 9 + k];
+    m3_inv<T>(m, o);
+#pragma unroll
+    for (int k = 0; k < 9; ++k) Dinv[(size_t)i * 9 + k] = o[k];
+}
+
+// P = Z - w Dinv (A Z), one thread per P block; Z_k = [[1,0,-ry],[0,1,rx],[0,0,1]] (rigid modes).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __restrict__ p_row, const int* __restrict__ p_self,
+                                                        const int* __restrict__ sptr, const int* __restrict__ sx, const int* __restrict__ sy,
+                                                        const T* __restrict__ A, const T* __restrict__ Dinv, const T* __restrict__ rel,
+                                                        T omega, T* __restrict__ P) {
+    const int pb = blockIdx.x * kBlock + threadIdx.x;
+    if (pb >= nnzP) return;
+    const int i = p_row[pb];
+    T acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = sptr[pb]; q < sptr[pb + 1]; ++q) {
+        const int k = sy[q];
+        const T zk[9] = {T(1), T(0), -rel[(size_t)k * 2 + 1], T(0), T(1), rel[(size_t)k * 2], T(0), T(0), T(1)};
+        T a[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) a[m] = A[(size_t)sx[q] * 9 + m];
+        m3_mul_acc<T>(a, zk, acc);
+    }
+    T d[9], da[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+    for (int m = 0; m < 9; ++m) d[m] = Dinv[(size_t)i * 9 + m];
+    m3_mul_acc<T>(d, acc, da);
+    T o[9];
+#pragma unroll
+    for (int m = 0; m < 9; ++m) o[m] = -omega * da[m];
+    if (p_self[pb]) { o[0] += T(1); o[4] += T(1); o[8] += T(1); o[2] -= rel[(size_t)i * 2 + 1]; o[5] += rel[(size_t)i * 2]; }
+#pragma unroll
+    for (int m = 0; m < 9; ++m) P[(size_t)pb * 9 + m] = o[m];
+}
+
+// out[o] = sum over its pair list of X[x] * Y[y]  (TRANS: X[x]^T * Y[y]); one thread per output block.
+template <typename T, int TRANS>
+__global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __restrict__ ptr, const int* __restrict__ px,
+                                                      const int* __restrict__ py, const T* __restrict__ X, const T* __restrict__ Y,
+                                                      T* __restrict__ out) {
+    const int o = blockIdx.x * kBlock + threadIdx.x;
+    if (o >= n_out) return;
+    T acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = ptr[o]; q < ptr[o + 1]; ++q) {
+        T a[9], b[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) { a[m] = X[(size_t)px[q] * 9 + m]; b[m] = Y[(size_t)py[q] * 9 + m]; }
+        if (TRANS) m3_tmul_acc<T>(a, b, acc); else m3_mul_acc<T>(a, b, acc);
+    }
+#pragma unroll
+    for (int m = 0; m < 9; ++m) out[(size_t)o * 9 + m] = acc[m];
+}
+
+// Dense inverse of the coarsest matrix in LDS (n <= 84), in-place Gauss-Jordan; SPD so no pivoting.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dense_inverse(int nb, const int* __restrict__ ptr, const int* __restrict__ col,
+                                                          const T* __restrict__ A, T* __restrict__ inv) {
+    __shared__ T M[kDenseMax * kDenseMax];
+    __shared__ T colk[kDenseMax];
+    const int n = nb * 3;
+    for (int e = threadIdx.x; e < n * n; e += kBlock) M[e] = T(0);
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += kBlock)
+        for (int a = ptr[i]; a < ptr[i + 1]; ++a)
+            for (int x = 0; x < 3; ++x)
+                for (int y = 0; y < 3; ++y) M[(3 * i + x) * n + 3 * col[a] + y] = A[(size_t)a * 9 + 3 * x + y];
+    __syncthreads();
+    for (int k = 0; k < n; ++k) {
+        const T piv = M[k * n + k];
+        const T ip = (fabs(piv) > T(0)) ? T(1) / piv : T(0);
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += kBlock) colk[i] = M[i * n + k];
+        __syncthreads();
+        for (int j = threadIdx.x; j < n; j += kBlock) M[k * n + j] = (j == k ? T(1) : M[k * n + j]) * ip;
+        __syncthreads();
+        for (int e = threadIdx.x; e < n * n; e += kBlock) {
+            const int i = e / n, j = e - i * n;
+            if (i != k) M[e] = (j == k ? T(0) : M[e]) - colk[i] * M[k * n + j];
+        }
+        __syncthreads();
+    }
+    for (int e = threadIdx.x; e < n * n; e += kBlock) inv[e] = M[e];
+}
+
+// ---- V-cycle ---------------------------------------------------------------------------------------
+// z = Dinv r (pre-smoothing from a zero guess), one thread per block row
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dinv_apply(int n, const T* __restrict__ Dinv, const T* __restrict__ r, T* __restrict__ z,
+                                                       const CgState<T>* __restrict__ st) {
+    if (st->done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const T* d = Dinv + (size_t)i * 9; const T r0 = r[(size_t)i * 3], r1 = r[(size_t)i * 3 + 1], r2 = r[(size_t)i * 3 + 2];
+    z[(size_t)i * 3] = d[0] * r0 + d[1] * r1 + d[2] * r2; z[(size_t)i * 3 + 1] = d[3] * r0 + d[4] * r1 + d[5] * r2;
+    z[(size_t)i * 3 + 2] = d[6] * r0 + d[7] * r1 + d[8] * r2;
+}
+
+// MODE 0: out = r - A z.   MODE 1: out = z + Dinv (r - A z)  (post-smoothing).  kLpr lanes per row.
+template <typename T, int MODE>
+__global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __restrict__ ptr, const int* __restrict__ col,
+                                                          const T* __restrict__ A, const T* __restrict__ r, const T* __restrict__ z,
+                                                          const T* __restrict__ Dinv, T* __restrict__ out,
+                                                          const CgState<T>* __restrict__ st) {
+    if (st->done) return;
+    const int g = (blockIdx.x * kBlock + threadIdx.x) / kLpr, sub = threadIdx.x % kLpr;
+    const int i = g < n ? g : n - 1;
+    T s0 = 0, s1 = 0, s2 = 0;
+    for (int a = ptr[i] + sub; a < ptr[i + 1]; a += kLpr) {
+        const T* b = A + (size_t)a * 9; const T* v = z + (size_t)col[a] * 3;
+        const T v0 = v[0], v1 = v[1], v2 = v[2];
+        s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
+    }
+    s0 = group_sum<T, kLpr>(s0); s1 = group_sum<T, kLpr>(s1); s2 = group_sum<T, kLpr>(s2);
+    if (g < n && sub == 0) {
+        const T e0 = r[(size_t)i * 3] - s0, e1 = r[(size_t)i * 3 + 1] - s1, e2 = r[(size_t)i * 3 + 2] - s2;
+        if (MODE == 0) { out[(size_t)i * 3] = e0; out[(size_t)i * 3 + 1] = e1; out[(size_t)i * 3 + 2] = e2; }
+        else {
+            const T* d = Dinv + (size_t)i * 9;
+            out[(size_t)i * 3] = z[(size_t)i * 3] + d[0] * e0 + d[1] * e1 + d[2] * e2;
+            out[(size_t)i * 3 + 1] = z[(size_t)i * 3 + 1] + d[3] * e0 + d[4] * e1 + d[5] * e2;
+            out[(size_t)i * 3 + 2] = z[(size_t)i * 3 + 2] + d[6] * e0 + d[7] * e1 + d[8] * e2;
+        }
+    }
+}
+
+// rc = P^T v over the rows of R = P^T.  SUB: v = a - b (level 0: r - S z, never materialised).
+template <typename T, int SUB>
+__global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
+                                                     const int* __restrict__ r_to_p, const T* __restrict__ P, const T* __restrict__ va,
+                                                     const T* __restrict__ vb, T* __restrict__ rc, const CgState<T>* __restrict__ st) {
+    if (st->done) return;
+    const int g = (blockIdx.x * kBlock + threadIdx.x) / kLpr, sub = threadIdx.x % kLpr;
+    const int a = g < n_agg ? g : n_agg - 1;
+    T s0 = 0, s1 = 0, s2 = 0;
+    for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += kLpr) {
+        const T* b = P + (size_t)r_to_p[rb] * 9; const size_t i = (size_t)rcol[rb] * 3;
+        T x0 = va[i], x1 = va[i + 1], x2 = va[i + 2];
+        if (SUB) { x0 -= vb[i]; x1 -= vb[i + 1]; x2 -= vb[i + 2]; }
+        s0 += b[0] * x0 + b[3] * x1 + b[6] * x2; s1 += b[1] * x0 + b[4] * x1 + b[7] * x2; s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+    }
+    s0 = group_sum<T, kLpr>(s0); s1 = group_sum<T, kLpr>(s1); s2 = group_sum<T, kLpr>(s2);
+    if (g < n_agg && sub == 0) { rc[(size_t)a * 3] = s0; rc[(size_t)a * 3 + 1] = s1; rc[(size_t)a * 3 + 2] = s2; }
+}
+
+// z_i += sum_a P_ia e_a, one thread per row; z has row stride `zs` (3 on coarse levels, kPoseRec for zc)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __restrict__ pptr, const int* __restrict__ pcol,
+                                                        const T* __restrict__ P, const T* __restrict__ e, T* __restrict__ z, int zs,
+                                                        const CgState<T>* __restrict__ st) {
+    if (st->done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    T s0 = 0, s1 = 0, s2 = 0;
+    for (int pb = pptr[i]; pb < pptr[i + 1]; ++pb) {
+        const T* b = P + (size_t)pb * 9; const T* v = e + (size_t)pcol[pb] * 3;
+        const T v0 = v[0], v1 = v[1], v2 = v[2];
+        s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
+    }
+    z[(size_t)i * zs] += s0; z[(size_t)i * zs + 1] += s1; z[(size_t)i * zs + 2] += s2;
+}
+
+// coarsest level: z = inv r, one thread per row (n <= 84), single workgroup
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_dense_apply(int n, const T* __restrict__ inv, const T* __restrict__ r, T* __restrict__ z,
+                                                        const CgState<T>* __restrict__ st) {
+    if (st->done) return;
+    __shared__ T rv[kDenseMax];
+    for (int j = threadIdx.x; j < n; j += kBlock) rv[j] = r[j];
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < n) { T s = 0; for (int j = 0; j < n; ++j) s += inv[(size_t)i * n + j] * rv[j]; z[i] = s; }
+}
+
+// level 0 smoothing with the symmetric 3x3 inverse blocks of the Schur diagonal (minv, 6 per pose):
+//   MODE 0: zc = Minv r              (pre-smoothing, zero guess)
+//   MODE 1: zc += Minv (r - s)       (post-smoothing; s = S zc from the implicit passes)
+template <typename T, int MODE>
+__global__ __launch_bounds__(kBlock) void k_smooth0(int P, const T* __restrict__ minv, const T* __restrict__ r, const T* __restrict__ s,
+                                                    T* __restrict__ zc, const CgState<T>* __restrict__ st) {
+    if (st->done) return;
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    T e0 = r[(size_t)i * 3], e1 = r[(size_t)i * 3 + 1], e2 = r[(size_t)i * 3 + 2];
+    if (MODE == 1) { e0 -= s[(size_t)i * 3]; e1 -= s[(size_t)i * 3 + 1]; e2 -= s[(size_t)i * 3 + 2]; }
+    T z0, z1, z2;
+    sym3_mul<T>(minv + (size_t)i * 6, e0, e1, e2, z0, z1, z2);
+    T* zr = zc + (size_t)i * kPoseRec;
+    if (MODE == 0) { zr[0] = z0; zr[1] = z1; zr[2] = z2; } else { zr[0] += z0; zr[1] += z1; zr[2] += z2; }
+}
+
+// PCG vector step when the preconditioner is applied by separate kernels (the V-cycle):
+//   gamma = (r, z), delta = (S z, z) arrive as partials; p = z + beta p, q = S z + beta q,
+//   x += alpha p, r -= alpha q.  z for the next iteration comes from the next V-cycle.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__ sz, const T* __restrict__ dot_part,
+                                                    const T* __restrict__ rz_part, int n_part, const CgState<T>* __restrict__ st_in,
+                                                    CgState<T>* __restrict__ st_out, T* __restrict__ r, T* __restrict__ p,
+                                                    T* __restrict__ q, T* __restrict__ x, const T* __restrict__ zc, T tol2, int max_iters) {
+    __shared__ T red[kWavesPerBlock];
+    const CgState<T> s = *st_in;
+    const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
+    if (s.done) { if (writer) *st_out = s; return; }
+    const T delta = block_sum_array<T>(dot_part, n_part, red);
+    const T gamma = block_sum_array<T>(rz_part, n_part, red);
+    const T gamma0 = s.iters == 0 ? gamma : s.gamma0;
+    CgState<T> n = s; n.gamma0 = gamma0;
+    if (!(gamma > tol2 * gamma0) || s.iters >= max_iters) {
+        n.done = 1; n.fail = (gamma != gamma) ? 1 : ((gamma > tol2 * gamma0) ? 2 : 0);
+        if (writer) *st_out = n;
+        return;
+    }
+    T beta, alpha;
+    if (s.iters == 0) { beta = 0; alpha = gamma / delta; }
+    else { beta = gamma / s.gamma_old; alpha = gamma / (delta - beta * gamma / s.alpha_old); }
+    if (!(alpha > 0) || !(alpha < T(1e300))) { n.done = 1; n.fail = 1; if (writer) *st_out = n; return; }
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i < P) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const size_t j = (size_t)i * 3 + k;
+            const T pk = zc[(size_t)i * kPoseRec + k] + beta * p[j];
+            const T qk = sz[j] + beta * q[j];
+            p[j] = pk; q[j] = qk; x[j] += alpha * pk; r[j] -= alpha * qk;
+        }
+    }
+    if (writer) { n.gamma_old = gamma; n.alpha_old = alpha; n.iters = s.iters + 1; *st_out = n; }
+}
+
+}  // namespace tsgo

@@ -16,8 +16,10 @@
 #include <vector>
 
 #include "../../include/tsgo.h"
+#include "host/amg.h"
 #include "host/errors.h"
 #include "host/problem.h"
+#include "tsgo_amg_kernels.h"
 #include "tsgo_kernels.h"
 
 namespace {
@@ -69,6 +71,17 @@ struct IEngine {
 };
 
 constexpr int kChunk = 16;   // PCG iterations per captured hipGraph (even: the state ring has 2 slots)
+constexpr int kChunkAmg = 4; // with the multigrid V-cycle an iteration is ~30 launches and a solve ~50 iterations
+
+template <typename T> struct DevLevel {      // device copy of one AmgLevel (host/amg.h) + its numeric arrays
+    int n = 0, n_agg = 0, nnzA = 0, nnzP = 0, nnzT = 0, nnzNext = 0;
+    int *A_ptr = nullptr, *A_col = nullptr, *A_row = nullptr, *diag = nullptr;
+    int *P_ptr = nullptr, *P_col = nullptr, *P_row = nullptr, *p_self = nullptr, *ps_ptr = nullptr, *ps_x = nullptr, *ps_y = nullptr;
+    int *R_ptr = nullptr, *R_col = nullptr, *r_to_p = nullptr;
+    int *ts_ptr = nullptr, *ts_x = nullptr, *ts_y = nullptr, *as_ptr = nullptr, *as_x = nullptr, *as_y = nullptr;
+    T *rel = nullptr, *A = nullptr, *Dinv = nullptr, *P = nullptr, *Tv = nullptr;
+    T *r = nullptr, *z = nullptr, *res = nullptr, *z2 = nullptr;
+};
 
 template <typename T> struct Engine : IEngine {
     tsgo_config cfg;
@@ -90,6 +103,14 @@ template <typename T> struct Engine : IEngine {
     hipGraphExec_t cg_graph = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int predicted_cg = 0;
+    // multigrid preconditioner (single shard)
+    bool amg_on = false;
+    AmgSym amg;
+    std::vector<DevLevel<T>> lv;
+    int *sc_ptr = nullptr, *sc_optr = nullptr; uint32_t *sc_si = nullptr, *sc_sk = nullptr, *sc_os = nullptr;
+    int *last_ptr = nullptr, *last_col = nullptr; int nb_last = 0, nnz_last = 0;
+    T *A_last = nullptr, *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr;
+    double ms_amg_symbolic = 0;
 
     explicit Engine(const tsgo_config& c) : cfg(c) {}
 
@@ -133,6 +154,65 @@ template <typename T> struct Engine : IEngine {
         *out = d;
         return 0;
     }
+    int upload_i32(int** out, const std::vector<int>& v) {
+        if (int rc = dalloc(out, v.size())) return rc;
+        if (!v.empty()) HIP_OK(hipMemcpy(*out, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+        return 0;
+    }
+    int upload_u32m(uint32_t** out, const std::vector<uint32_t>& v) {
+        if (int rc = dalloc(out, v.size())) return rc;
+        if (!v.empty()) HIP_OK(hipMemcpy(*out, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        return 0;
+    }
+    static std::vector<int> rows_of(const BlockCsr& m) {
+        std::vector<int> r(m.col.size());
+        for (int i = 0; i < m.n_rows; ++i) for (int a = m.ptr[i]; a < m.ptr[i + 1]; ++a) r[a] = i;
+        return r;
+    }
+    int upload_amg() {
+        const auto t0 = std::chrono::steady_clock::now();
+        const std::string err = build_amg(pr, amg);
+        if (!err.empty()) return set_error(-2, "tsgo_set_graph: " + err);
+        ms_amg_symbolic = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        lv.assign(amg.levels.size(), DevLevel<T>());
+#define UP(dst, vec) if (int rc = upload_i32(&dst, vec)) return rc
+        for (size_t l = 0; l < amg.levels.size(); ++l) {
+            const AmgLevel& L = amg.levels[l]; DevLevel<T>& D = lv[l];
+            D.n = L.n; D.n_agg = L.n_agg; D.nnzA = L.A.nnz(); D.nnzP = L.P.nnz(); D.nnzT = L.T.nnz(); D.nnzNext = (int)L.a_src.ptr.size() - 1;
+            UP(D.A_ptr, L.A.ptr); UP(D.A_col, L.A.col); UP(D.A_row, rows_of(L.A)); UP(D.diag, L.diag);
+            UP(D.P_ptr, L.P.ptr); UP(D.P_col, L.P.col); UP(D.P_row, rows_of(L.P)); UP(D.p_self, L.p_self);
+            UP(D.ps_ptr, L.p_src.ptr); UP(D.ps_x, L.p_src.x); UP(D.ps_y, L.p_src.y);
+            UP(D.R_ptr, L.R.ptr); UP(D.R_col, L.R.col); UP(D.r_to_p, L.r_to_p);
+            UP(D.ts_ptr, L.t_src.ptr); UP(D.ts_x, L.t_src.x); UP(D.ts_y, L.t_src.y);
+            UP(D.as_ptr, L.a_src.ptr); UP(D.as_x, L.a_src.x); UP(D.as_y, L.a_src.y);
+            if (int rc = upload_T(&D.rel, L.rel.data(), L.rel.size())) return rc;
+            if (int rc = dalloc(&D.A, (size_t)D.nnzA * 9)) return rc;
+            if (int rc = dalloc(&D.Dinv, (size_t)D.n * 9)) return rc;
+            if (int rc = dalloc(&D.P, (size_t)D.nnzP * 9)) return rc;
+            if (int rc = dalloc(&D.Tv, (size_t)D.nnzT * 9)) return rc;
+            if (l > 0) {
+                if (int rc = dalloc(&D.r, (size_t)D.n * 3)) return rc;
+                if (int rc = dalloc(&D.z, (size_t)D.n * 3)) return rc;
+                if (int rc = dalloc(&D.res, (size_t)D.n * 3)) return rc;
+                if (int rc = dalloc(&D.z2, (size_t)D.n * 3)) return rc;
+            }
+        }
+        UP(sc_ptr, amg.schur.ptr); UP(sc_optr, amg.schur.od_ptr);
+        if (int rc = upload_u32m(&sc_si, amg.schur.slot_i)) return rc;
+        if (int rc = upload_u32m(&sc_sk, amg.schur.slot_k)) return rc;
+        if (int rc = upload_u32m(&sc_os, amg.schur.od_slot)) return rc;
+        UP(last_ptr, amg.A_last.ptr); UP(last_col, amg.A_last.col);
+#undef UP
+        nb_last = amg.A_last.n_rows; nnz_last = amg.A_last.nnz();
+        if (nb_last * 3 > kDenseMax) return set_error(-2, "tsgo_set_graph: coarsest multigrid level too large");
+        if (int rc = dalloc(&A_last, (size_t)nnz_last * 9)) return rc;
+        if (int rc = dalloc(&inv_last, (size_t)nb_last * 3 * nb_last * 3)) return rc;
+        if (int rc = dalloc(&r_last, (size_t)nb_last * 3)) return rc;
+        if (int rc = dalloc(&z_last, (size_t)nb_last * 3)) return rc;
+        if (int rc = dalloc(&rzpart, (size_t)nbP)) return rc;
+        return 0;
+    }
+
     int upload_table(Table<T>& t, const SellTable& h, int dyn_planes) {
         t.slots = h.slots(); t.n_slices = h.n_slices; t.n_vertices = h.n_vertices;
         if (int rc = upload_u32(&t.row_off, h.row_off)) return rc;
@@ -192,6 +272,9 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, nbC) + nbL + 8)));
         HIP_OK(hipDeviceSynchronize());
+        amg_on = cfg.preconditioner == 1 && pr.world == 1 && pr.P > kCoarsestMax;
+        if (amg_on) { if (int rc = upload_amg()) return rc; }
+        HIP_OK(hipDeviceSynchronize());
         have_graph_data = true;
         predicted_cg = 0;
         if (cfg.use_graphs && pr.world == 1) { if (int rc = capture_cg_graph()) return rc; }
@@ -207,10 +290,79 @@ template <typename T> struct Engine : IEngine {
     void launch_finalize() {
         hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0]);
     }
-    void launch_matvec(int slot) {   // S * (vector in zc) -> sbuf, dot partials behind it
+    void launch_matvec(int slot, bool with_rz = false) {   // S * (vector in zc) -> sbuf, dot partials behind it
         if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, tvec, st[slot], T(0), dl, npart);
-        LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot]);
+        LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
+                 (const T*)(with_rz ? r : nullptr), rzpart);
     }
+    static int grid_for(int n, int per_thread_lanes = 1) { return std::max(1, (int)(((size_t)n * per_thread_lanes + kBlock - 1) / kBlock)); }
+
+    // numeric multigrid setup for the current linearisation (after lin + finalize)
+    void launch_amg_setup() {
+        DevLevel<T>& L0 = lv[0];
+        hipLaunchKernelGGL((k_schur_blocks<T>), dim3(grid_for(L0.nnzA)), dim3(kBlock), 0, stream, L0.nnzA, L0.A_row, L0.A_col, sc_ptr, sc_si, sc_sk,
+                           sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A);
+        for (size_t l = 0; l < lv.size(); ++l) {
+            DevLevel<T>& L = lv[l];
+            T* Anext = l + 1 < lv.size() ? lv[l + 1].A : A_last;
+            hipLaunchKernelGGL((k_block_inv<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.diag, (const T*)L.A, L.Dinv);
+            hipLaunchKernelGGL((k_prolongator<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, L.P_row, L.p_self, L.ps_ptr, L.ps_x, L.ps_y,
+                               (const T*)L.A, (const T*)L.Dinv, (const T*)L.rel, (T)kProlongOmega, L.P);
+            hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for(L.nnzT)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const T*)L.A, (const T*)L.P, L.Tv);
+            hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for(L.nnzNext)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const T*)L.P, (const T*)L.Tv, Anext);
+        }
+        hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kBlock), 0, stream, nb_last, last_ptr, last_col, (const T*)A_last, inv_last);
+    }
+
+    // zc[.][0..2] = V(1,1)-cycle(r): the preconditioner application of one PCG iteration
+    void launch_vcycle(int slot) {
+        const CgState<T>* s = st[slot];
+        const int P = pr.P;
+        const size_t nl = lv.size();
+        hipLaunchKernelGGL((k_smooth0<T, 0>), dim3(nbC), dim3(kBlock), 0, stream, P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, s);
+        launch_matvec(slot);
+        {   // restrict r - S z to level 1 (or to the dense level)
+            DevLevel<T>& L = lv[0];
+            T* rc = nl > 1 ? lv[1].r : r_last;
+            hipLaunchKernelGGL((k_restrict<T, 1>), dim3(grid_for(L.n_agg, kLpr)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P,
+                               (const T*)r, (const T*)sbuf, rc, s);
+        }
+        for (size_t l = 1; l < nl; ++l) {
+            DevLevel<T>& L = lv[l];
+            T* rc = l + 1 < nl ? lv[l + 1].r : r_last;
+            hipLaunchKernelGGL((k_dinv_apply<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, (const T*)L.Dinv, (const T*)L.r, L.z, s);
+            hipLaunchKernelGGL((k_bcsr_residual<T, 0>), dim3(grid_for(L.n, kLpr)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r,
+                               (const T*)L.z, (const T*)L.Dinv, L.res, s);
+            hipLaunchKernelGGL((k_restrict<T, 0>), dim3(grid_for(L.n_agg, kLpr)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P,
+                               (const T*)L.res, (const T*)L.res, rc, s);
+        }
+        hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
+        for (size_t l = nl - 1; l >= 1; --l) {
+            DevLevel<T>& L = lv[l];
+            const T* e = l + 1 < nl ? lv[l + 1].z2 : z_last;
+            hipLaunchKernelGGL((k_prolong_add<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, L.z, 3, s);
+            hipLaunchKernelGGL((k_bcsr_residual<T, 1>), dim3(grid_for(L.n, kLpr)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r,
+                               (const T*)L.z, (const T*)L.Dinv, L.z2, s);
+        }
+        {
+            DevLevel<T>& L = lv[0];
+            const T* e = nl > 1 ? lv[1].z2 : z_last;
+            hipLaunchKernelGGL((k_prolong_add<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, zc, kPoseRec, s);
+        }
+        launch_matvec(slot);
+        hipLaunchKernelGGL((k_smooth0<T, 1>), dim3(nbC), dim3(kBlock), 0, stream, P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, s);
+    }
+    void launch_cg_step(int slot) {
+        const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
+        hipLaunchKernelGGL((k_cg_step<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)(sbuf + (size_t)pr.P * 3), (const T*)rzpart, nbP,
+                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, (const T*)zc, tol2, cfg.pcg_max_iters);
+    }
+    // one PCG iteration reading state slot `slot`, writing slot^1
+    void launch_iteration(int slot) {
+        if (amg_on) { launch_vcycle(slot); launch_matvec(slot, true); launch_cg_step(slot); }
+        else { launch_matvec(slot); launch_cg_update(slot); }
+    }
+    int chunk() const { return amg_on ? kChunkAmg : kChunk; }
     void launch_cg_update(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
         hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[slot], nbC,
@@ -225,7 +377,7 @@ template <typename T> struct Engine : IEngine {
     int capture_cg_graph() {
         hipGraph_t graph = nullptr;
         HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        for (int j = 0; j < kChunk; ++j) { launch_matvec(j & 1); launch_cg_update(j & 1); }
+        for (int j = 0; j < chunk(); ++j) launch_iteration(j & 1);
         HIP_OK(hipStreamEndCapture(stream, &graph));
         HIP_OK(hipGraphInstantiate(&cg_graph, graph, nullptr, nullptr, 0));
         HIP_OK(hipGraphDestroy(graph));
@@ -237,6 +389,7 @@ template <typename T> struct Engine : IEngine {
         launch_lin();
         if (int rc = allreduce(part, (size_t)pr.P * 18 + nbP)) return rc;
         launch_finalize();
+        if (amg_on) launch_amg_setup();
         HIP_OK(hipMemcpyAsync(h_scratch, part + (size_t)pr.P * 18, sizeof(T) * nbP, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
         double s = 0;
@@ -248,22 +401,24 @@ template <typename T> struct Engine : IEngine {
     // PCG until the device state says done.  The state ring is at slot 0 on entry and on exit.
     int do_solve(int* iters, int* fail) {
         int launched = 0;
-        int burst = std::max(1, (int)(0.9 * predicted_cg) / kChunk);    // chunks before the first look
+        const int ch = chunk();
+        int burst = std::max(1, (int)(0.9 * predicted_cg) / ch);    // chunks before the first look
         for (;;) {
             for (int b = 0; b < burst; ++b) {
                 if (cg_graph) HIP_OK(hipGraphLaunch(cg_graph, stream));
-                else for (int j = 0; j < kChunk; ++j) {
+                else if (amg_on) for (int j = 0; j < ch; ++j) launch_iteration(j & 1);
+                else for (int j = 0; j < ch; ++j) {
                     launch_matvec(j & 1);
                     if (int rc = allreduce(sbuf, (size_t)pr.P * 3 + nbP)) return rc;
                     launch_cg_update(j & 1);
                 }
-                launched += kChunk;
+                launched += ch;
             }
             burst = 1;
             HIP_OK(hipMemcpyAsync(h_state, st[0], sizeof(CgState<T>), hipMemcpyDeviceToHost, stream));
             HIP_OK(hipStreamSynchronize(stream));
             if (h_state->done) break;
-            if (launched > cfg.pcg_max_iters + 2 * kChunk) return set_error(-20, "PCG did not terminate");
+            if (launched > cfg.pcg_max_iters + 2 * ch) return set_error(-20, "PCG did not terminate");
         }
         *iters = h_state->iters; *fail = h_state->fail;
         predicted_cg = h_state->iters;
@@ -423,7 +578,7 @@ template <typename T> struct Engine : IEngine {
             for (int k = 0; k < n; ++k) {
                 switch (which) {
                     case 0: if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, tvec, st[0], T(0), dl, npart); break;
-                    case 1: LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[0]); break;
+                    case 1: LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[0], (const T*)nullptr, (T*)nullptr); break;
                     case 2: {   // state slot 1 is never written here, slot 0 stays "iters = 0, not done"
                         const T tol2 = (T)0;
                         hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[0], nbC,
@@ -432,7 +587,8 @@ template <typename T> struct Engine : IEngine {
                     }
                     case 3: if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l); break;
                     case 4: LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18); break;
-                    default: launch_matvec(0); launch_cg_update(0); launch_matvec(1); launch_cg_update(1); break;
+                    case 6: if (amg_on) launch_amg_setup(); break;
+                    default: launch_iteration(0); launch_iteration(1); break;
                 }
             }
             HIP_OK(hipEventRecord(ev[1], stream));
@@ -440,12 +596,12 @@ template <typename T> struct Engine : IEngine {
             if (pass == 1) {
                 float ms = 0;
                 HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[1]));
-                const double per = which >= 5 ? 2.0 * n : (double)n;
+                const double per = which == 5 ? 2.0 * n : (double)n;
                 *us = 1e3 * ms / per;
             }
         }
-        const double tab[6] = {b_lm, b_pose, b_upd, b_linlm, b_linpose, b_lm + b_pose + b_upd};
-        *bytes = tab[std::min(std::max(which, 0), 5)];
+        const double tab[7] = {b_lm, b_pose, b_upd, b_linlm, b_linpose, (amg_on ? 3.0 : 1.0) * (b_lm + b_pose) + b_upd, 0.0};
+        *bytes = tab[std::min(std::max(which, 0), 6)];
         // leave a consistent state behind
         return do_linearize(&chi2);
     }

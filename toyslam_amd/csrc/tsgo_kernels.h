@@ -305,7 +305,8 @@ template <typename T, int G>
 __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od, const T* __restrict__ zc,
                                                        const T* __restrict__ t, const T* __restrict__ dp,
                                                        int pose_first, int pose_last, T* __restrict__ out,
-                                                       T* __restrict__ dot_part, const CgState<T>* __restrict__ st) {
+                                                       T* __restrict__ dot_part, const CgState<T>* __restrict__ st,
+                                                       const T* __restrict__ rvec, T* __restrict__ rz_part) {
     __shared__ T red[kWavesPerBlock];
     if (st->done) return;
     const int slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
@@ -313,7 +314,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;
     const int i = slice * VPS + lane / G;
-    T dot = 0;
+    T dot = 0, rz = 0;
     if (live) {
         const bool valid = i < tb.n_vertices;
         const int ic = valid ? i : tb.n_vertices - 1;
@@ -355,10 +356,15 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
             }
             out[(size_t)i * 3] = o0; out[(size_t)i * 3 + 1] = o1; out[(size_t)i * 3 + 2] = o2;
             dot = o0 * v0 + o1 * v1 + o2 * v2;
+            if (rvec) rz = rvec[(size_t)i * 3] * v0 + rvec[(size_t)i * 3 + 1] * v1 + rvec[(size_t)i * 3 + 2] * v2;
         }
     }
     const T total = block_sum<T>(dot, red);
     if (threadIdx.x == 0) dot_part[blockIdx.x] = total;
+    if (rvec) {        // wave-uniform: a kernel argument
+        const T trz = block_sum<T>(rz, red);
+        if (threadIdx.x == 0) rz_part[blockIdx.x] = trz;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -42,11 +42,11 @@ def cpu_baseline(g, threads):
     oracle.set_threads(threads)
     o = util.to_oracle(g)
     t0 = time.time()
-    r = oracle.sparse_optimize(o, 1, pcg_tol=ARGS.pcg_tol)
+    r = oracle.sparse_optimize(o, 1, pcg_tol=ARGS.pcg_tol, precond=ARGS.precond)
     dt = time.time() - t0
     return {"value": len(g.e_type) / dt, "unit": "edges/s per GN iter", "cores": threads, "kind": "port",
-            "sample": "GN iteration 0 of the same %s graph: linearise + %d PCG iterations (tol %g) + update, %.1f s"
-                      % (ARGS.workload, int(r["cg_iters"][0]), ARGS.pcg_tol, dt),
+            "sample": "GN iteration 0 of the same %s graph, same algorithm (%s-preconditioned Schur PCG): linearise + %d PCG iterations (tol %g) + update, %.1f s incl. %.1f s host setup"
+                      % (ARGS.workload, ARGS.precond, int(r["cg_iters"][0]), ARGS.pcg_tol, dt, dt - r["seconds_linearize"] - r["seconds_solve"]),
             "pcg_iters": int(r["cg_iters"][0]), "seconds": dt}
 
 
@@ -69,7 +69,8 @@ def main():
     g = synth.make_config(ARGS.workload, seed=0)
     n_edges = len(g.e_type)
     opt = HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol, rank=rank, world=world,
-                       use_graphs=not ARGS.no_graphs, lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm)
+                       use_graphs=not ARGS.no_graphs, lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
+                       preconditioner=ARGS.precond)
     if world > 1:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -105,9 +106,11 @@ def main():
         # dominant kernel: the one with the largest share of a GN iteration
         n_cg = float(np.mean(timed_cg)) if timed_cg else 0.0
         shares = {}
+        amg = ARGS.precond == "amg" and world == 1
         for which in (0, 1, 2, 3, 4):
             us, nbytes = opt.time_kernel(which, reps=200)
-            per_iter = us * (n_cg if which < 3 else 1.0)
+            launches = {0: 3.0 if amg else 1.0, 1: 3.0 if amg else 1.0, 2: 0.0 if amg else 1.0}     # per PCG iteration
+            per_iter = us * (n_cg * launches[which] if which < 3 else 1.0)
             shares[which] = (per_iter, us, nbytes)
         dom = max(shares, key=lambda k: shares[k][0])
         _, us, nbytes = shares[dom]
@@ -119,7 +122,8 @@ def main():
             "dtype": "f64" if ARGS.precision == 64 else "f32", "data": "synthetic",
             "config": {"workload": "%s: %d poses / %d landmarks / %d ODOM + %d LM edges, seeded synthetic 2-D SLAM graph"
                                    % (ARGS.workload, g.n_poses, g.n_landmarks, int((g.e_type == 0).sum()), int((g.e_type == 1).sum())),
-                       "solver": "implicit-Schur PCG (Chronopoulos-Gear), block-Jacobi on the Schur diagonal, rel tol %g" % ARGS.pcg_tol,
+                       "solver": "implicit-Schur PCG (Chronopoulos-Gear), %s, rel tol %g"
+                                 % ("smoothed-aggregation multigrid V(1,1) preconditioner" if (ARGS.precond == "amg" and world == 1) else "block-Jacobi on the Schur diagonal", ARGS.pcg_tol),
                        "parallelism": "edge-sharded x%d" % world if world > 1 else "single GPU",
                        "hipgraph": not ARGS.no_graphs},
             "gn_iters_per_s": ARGS.steps / dt,
@@ -128,7 +132,9 @@ def main():
             "ms_per_step_device": {"linearize": ms_lin / ARGS.steps, "solve": ms_solve / ARGS.steps, "update": ms_upd / ARGS.steps},
             "roofline": {"bound": "hbm", "kernel": KERNELS[dom], "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "us_per_launch": us, "algorithmic_bytes_per_launch": nbytes,
-                         "all_kernels_us": {KERNELS[k]: shares[k][1] for k in shares}},
+                         "all_kernels_us": {KERNELS[k]: shares[k][1] for k in shares},
+                         "us_per_pcg_iteration": opt.time_kernel(5, reps=20)[0],
+                         "us_multigrid_numeric_setup": opt.time_kernel(6, reps=5)[0] if amg else None},
         }
         if world == 1 and not ARGS.no_cpu:
             out["cpu_baseline"] = cpu_baseline(g, ARGS.cpu_threads or min(16, len(os.sched_getaffinity(0))))
@@ -147,7 +153,8 @@ if __name__ == "__main__":
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="c3_100k")
     ap.add_argument("--precision", type=int, default=64)
-    ap.add_argument("--pcg-tol", dest="pcg_tol", type=float, default=1e-8)
+    ap.add_argument("--pcg-tol", dest="pcg_tol", type=float, default=1e-10)
+    ap.add_argument("--precond", default="amg", choices=["amg", "jacobi"])
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true")
     ap.add_argument("--no-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0)

@@ -165,6 +165,17 @@ typedef struct tsgo_layout_info {
 int tsgo_layout_probe(const tsgo_graph* g, int32_t rank, int32_t world, int32_t lanes_per_pose,
                       int32_t lanes_per_lm, tsgo_layout_info* out);
 
+/* ---- host-only: multigrid hierarchy probe (tests + setup timing) ------------------------------------*/
+typedef struct tsgo_amg_info {
+    int32_t n_levels;               /* matrices in the hierarchy, the dense coarsest one included */
+    int64_t rows[8];                /* block rows per level (level 0 = poses) */
+    int64_t blocks[8];              /* 3x3 blocks per level */
+    int64_t p_blocks[8];            /* blocks of the prolongator leaving each level */
+    int64_t schur_contribs;         /* landmark-pair terms summed into the explicit level-0 matrix */
+    double ms_layout, ms_symbolic;  /* host time: slot tables / hierarchy patterns */
+} tsgo_amg_info;
+int tsgo_amg_probe(const tsgo_graph* g, tsgo_amg_info* out);
+
 #ifdef __cplusplus
 }
 #endif

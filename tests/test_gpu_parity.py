@@ -126,11 +126,11 @@ def test_c2_10k_poses_against_sparse_cpu_twin(precond):
 
 
 def test_bench_tolerance_meets_the_north_star_bar():
-    """bench.py runs PCG at rel tol 1e-8: final chi^2 (relative) and poses (absolute) stay within 1e-6 of
+    """bench.py runs PCG at rel tol 1e-10 (1e-8 leaves 1.5e-6 on config-2 poses): final chi^2 (relative) and poses (absolute) stay within 1e-6 of
     the dense cpu/eigen restatement on config 1 and of the tightly converged twin on config 2."""
     g = util.c1_arrays()
     ref = oracle.optimize(util.to_oracle(g), 50, mode="cpp", solver="chol")
-    o = HipOptimizer(pcg_rel_tol=1e-8)
+    o = HipOptimizer(pcg_rel_tol=1e-10)
     try:
         o.set_graph(g)
         r = o.optimize(50)

@@ -35,9 +35,14 @@ class tsgo_layout_info(C.Structure):
                [(n, C.c_int64) for n in ("lm_first", "lm_last", "pose_first", "pose_last")]
 
 
+class tsgo_amg_info(C.Structure):
+    _fields_ = [("n_levels", C.c_int32), ("rows", C.c_int64 * 8), ("blocks", C.c_int64 * 8), ("p_blocks", C.c_int64 * 8),
+                ("schur_contribs", C.c_int64), ("ms_layout", C.c_double), ("ms_symbolic", C.c_double)]
+
+
 HOST_SYMBOLS = ["tsgo_default_config", "tsgo_last_error", "tsgo_wire_decode", "tsgo_wire_view", "tsgo_wire_free",
                 "tsgo_wire_encode_response", "tsgo_wire_encode_request", "tsgo_synth_create", "tsgo_synth_view",
-                "tsgo_synth_truth", "tsgo_synth_free", "tsgo_layout_probe"]
+                "tsgo_synth_truth", "tsgo_synth_free", "tsgo_layout_probe", "tsgo_amg_probe"]
 DEVICE_SYMBOLS = ["tsgo_create", "tsgo_destroy", "tsgo_set_graph", "tsgo_optimize", "tsgo_get_vertices",
                   "tsgo_linearize", "tsgo_solve_step", "tsgo_comm_unique_id", "tsgo_comm_init", "tsgo_time_kernel"]
 
@@ -57,6 +62,7 @@ def _declare_host(L):
     L.tsgo_synth_free.argtypes = [vp]; L.tsgo_synth_free.restype = None
     L.tsgo_layout_probe.argtypes = [C.POINTER(tsgo_graph), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.POINTER(tsgo_layout_info)]
+    L.tsgo_amg_probe.argtypes = [C.POINTER(tsgo_graph), C.POINTER(tsgo_amg_info)]
     del u8p
 
 

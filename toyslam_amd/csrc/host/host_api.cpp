@@ -2,6 +2,9 @@
 #include "../../../include/tsgo.h"
 #include "errors.h"
 #include "problem.h"
+#include "amg.h"
+#include <chrono>
+#include <cstring>
 
 extern "C" void tsgo_default_config(tsgo_config* c) {
     if (!c) return;
@@ -22,5 +25,27 @@ extern "C" int tsgo_layout_probe(const tsgo_graph* g, int32_t rank, int32_t worl
     out->rows_by_pose = (int64_t)pr.by_pose.rows; out->rows_by_lm = (int64_t)pr.by_lm.rows; out->rows_odom = (int64_t)pr.odom.rows;
     out->lanes_per_pose = pr.by_pose.G; out->lanes_per_lm = pr.by_lm.G;
     out->lm_first = pr.lm_first; out->lm_last = pr.lm_last; out->pose_first = pr.pose_first; out->pose_last = pr.pose_last;
+    return 0;
+}
+
+extern "C" int tsgo_amg_probe(const tsgo_graph* g, tsgo_amg_info* out) {
+    if (!g || !out) return tsgo::set_error(-1, "tsgo_amg_probe: null argument");
+    std::memset(out, 0, sizeof(*out));
+    tsgo::Problem pr; tsgo::BuildOptions bo;
+    auto t0 = std::chrono::steady_clock::now();
+    std::string err = tsgo::build_problem(*g, bo, pr);
+    if (!err.empty()) return tsgo::set_error(-2, err);
+    auto t1 = std::chrono::steady_clock::now();
+    tsgo::AmgSym amg;
+    err = tsgo::build_amg(pr, amg);
+    if (!err.empty()) return tsgo::set_error(-2, err);
+    auto t2 = std::chrono::steady_clock::now();
+    out->ms_layout = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    out->ms_symbolic = std::chrono::duration<double, std::milli>(t2 - t1).count();
+    int n = 0;
+    for (const auto& L : amg.levels) if (n < 8) { out->rows[n] = L.n; out->blocks[n] = L.A.nnz(); out->p_blocks[n] = L.P.nnz(); ++n; }
+    if (n < 8) { out->rows[n] = amg.A_last.n_rows; out->blocks[n] = amg.A_last.nnz(); ++n; }
+    out->n_levels = n;
+    out->schur_contribs = (int64_t)amg.schur.slot_i.size();
     return 0;
 }

@@ -12,7 +12,6 @@
 
 namespace tsgo {
 
-constexpr int kLpr = 8;                  // lanes cooperating on one block row in the block-CSR kernels
 constexpr int kDenseMax = 84;            // coarsest matrix is at most 84 x 84 (host/amg.h: kCoarsestMax * 3)
 
 template <typename T> __device__ __forceinline__ void m3_mul_acc(const T* a, const T* b, T* c) {
@@ -179,34 +178,26 @@ __global__ __launch_bounds__(kBlock) void k_dense_inverse(int nb, const int* __r
 }
 
 // ---- V-cycle ---------------------------------------------------------------------------------------
-// z = Dinv r (pre-smoothing from a zero guess), one thread per block row
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_dinv_apply(int n, const T* __restrict__ Dinv, const T* __restrict__ r, T* __restrict__ z,
-                                                       const CgState<T>* __restrict__ st) {
-    if (st->done) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const T* d = Dinv + (size_t)i * 9; const T r0 = r[(size_t)i * 3], r1 = r[(size_t)i * 3 + 1], r2 = r[(size_t)i * 3 + 2];
-    z[(size_t)i * 3] = d[0] * r0 + d[1] * r1 + d[2] * r2; z[(size_t)i * 3 + 1] = d[3] * r0 + d[4] * r1 + d[5] * r2;
-    z[(size_t)i * 3 + 2] = d[6] * r0 + d[7] * r1 + d[8] * r2;
-}
+// The coarse levels hold little work (12.5k / 1.5k / 196 block rows at 100k poses): what matters is the
+// length of the dependent-load chain, so LPR lanes share one block row (one 3x3 block per lane per
+// trip, 72 contiguous bytes per lane) and finish with an LPR-lane xor-shuffle sum.
 
-// MODE 0: out = r - A z.   MODE 1: out = z + Dinv (r - A z)  (post-smoothing).  kLpr lanes per row.
-template <typename T, int MODE>
+// MODE 0: out = r - A z.   MODE 1: out = z + Dinv (r - A z)  (post-smoothing).
+template <typename T, int LPR, int MODE>
 __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __restrict__ ptr, const int* __restrict__ col,
                                                           const T* __restrict__ A, const T* __restrict__ r, const T* __restrict__ z,
                                                           const T* __restrict__ Dinv, T* __restrict__ out,
                                                           const CgState<T>* __restrict__ st) {
     if (st->done) return;
-    const int g = (blockIdx.x * kBlock + threadIdx.x) / kLpr, sub = threadIdx.x % kLpr;
+    const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
-    for (int a = ptr[i] + sub; a < ptr[i + 1]; a += kLpr) {
+    for (int a = ptr[i] + sub; a < ptr[i + 1]; a += LPR) {
         const T* b = A + (size_t)a * 9; const T* v = z + (size_t)col[a] * 3;
         const T v0 = v[0], v1 = v[1], v2 = v[2];
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
-    s0 = group_sum<T, kLpr>(s0); s1 = group_sum<T, kLpr>(s1); s2 = group_sum<T, kLpr>(s2);
+    s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
     if (g < n && sub == 0) {
         const T e0 = r[(size_t)i * 3] - s0, e1 = r[(size_t)i * 3 + 1] - s1, e2 = r[(size_t)i * 3 + 2] - s2;
         if (MODE == 0) { out[(size_t)i * 3] = e0; out[(size_t)i * 3 + 1] = e1; out[(size_t)i * 3 + 2] = e2; }
@@ -219,43 +210,89 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
     }
 }
 
-// rc = P^T v over the rows of R = P^T.  SUB: v = a - b (level 0: r - S z, never materialised).
-template <typename T, int SUB>
+// rc = P^T v over the rows of R = P^T, and (when dinv_next is given) the next level's pre-smoothing
+// z_next = Dinv_next rc in the same pass.  SUB: v = a - b (level 0: r - S z, never materialised).
+template <typename T, int LPR, int SUB>
 __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
                                                      const int* __restrict__ r_to_p, const T* __restrict__ P, const T* __restrict__ va,
-                                                     const T* __restrict__ vb, T* __restrict__ rc, const CgState<T>* __restrict__ st) {
+                                                     const T* __restrict__ vb, T* __restrict__ rc, const T* __restrict__ dinv_next,
+                                                     T* __restrict__ z_next, const CgState<T>* __restrict__ st) {
     if (st->done) return;
-    const int g = (blockIdx.x * kBlock + threadIdx.x) / kLpr, sub = threadIdx.x % kLpr;
+    const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int a = g < n_agg ? g : n_agg - 1;
     T s0 = 0, s1 = 0, s2 = 0;
-    for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += kLpr) {
+    for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += LPR) {
         const T* b = P + (size_t)r_to_p[rb] * 9; const size_t i = (size_t)rcol[rb] * 3;
         T x0 = va[i], x1 = va[i + 1], x2 = va[i + 2];
         if (SUB) { x0 -= vb[i]; x1 -= vb[i + 1]; x2 -= vb[i + 2]; }
         s0 += b[0] * x0 + b[3] * x1 + b[6] * x2; s1 += b[1] * x0 + b[4] * x1 + b[7] * x2; s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
     }
-    s0 = group_sum<T, kLpr>(s0); s1 = group_sum<T, kLpr>(s1); s2 = group_sum<T, kLpr>(s2);
-    if (g < n_agg && sub == 0) { rc[(size_t)a * 3] = s0; rc[(size_t)a * 3 + 1] = s1; rc[(size_t)a * 3 + 2] = s2; }
+    s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
+    if (g < n_agg && sub == 0) {
+        rc[(size_t)a * 3] = s0; rc[(size_t)a * 3 + 1] = s1; rc[(size_t)a * 3 + 2] = s2;
+        if (dinv_next) {
+            const T* d = dinv_next + (size_t)a * 9;
+            z_next[(size_t)a * 3] = d[0] * s0 + d[1] * s1 + d[2] * s2; z_next[(size_t)a * 3 + 1] = d[3] * s0 + d[4] * s1 + d[5] * s2;
+            z_next[(size_t)a * 3 + 2] = d[6] * s0 + d[7] * s1 + d[8] * s2;
+        }
+    }
 }
 
-// z_i += sum_a P_ia e_a, one thread per row; z has row stride `zs` (3 on coarse levels, kPoseRec for zc)
-template <typename T>
+// z_i += sum_a P_ia e_a; z has row stride `zs` (3 on coarse levels, kPoseRec for zc)
+template <typename T, int LPR>
 __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __restrict__ pptr, const int* __restrict__ pcol,
                                                         const T* __restrict__ P, const T* __restrict__ e, T* __restrict__ z, int zs,
                                                         const CgState<T>* __restrict__ st) {
     if (st->done) return;
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
+    const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
+    const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
-    for (int pb = pptr[i]; pb < pptr[i + 1]; ++pb) {
+    for (int pb = pptr[i] + sub; pb < pptr[i + 1]; pb += LPR) {
         const T* b = P + (size_t)pb * 9; const T* v = e + (size_t)pcol[pb] * 3;
         const T v0 = v[0], v1 = v[1], v2 = v[2];
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
-    z[(size_t)i * zs] += s0; z[(size_t)i * zs + 1] += s1; z[(size_t)i * zs + 2] += s2;
+    s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
+    if (g < n && sub == 0) { z[(size_t)i * zs] += s0; z[(size_t)i * zs + 1] += s1; z[(size_t)i * zs + 2] += s2; }
 }
 
-// coarsest level: z = inv r, one thread per row (n <= 84), single workgroup
+// Bottom of the V-cycle in ONE workgroup: restrict the last explicit level's residual (n <= 224 rows)
+// to the dense level (<= 28 aggregates), apply the dense inverse, prolong the correction back.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_coarse_tail(int n, int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
+                                                        const int* __restrict__ r_to_p, const int* __restrict__ pptr,
+                                                        const int* __restrict__ pcol, const T* __restrict__ P, const T* __restrict__ res,
+                                                        const T* __restrict__ inv, T* __restrict__ z, const CgState<T>* __restrict__ st) {
+    if (st->done) return;
+    __shared__ T rc[kDenseMax], zc_[kDenseMax];
+    {
+        const int a = threadIdx.x / 8, sub = threadIdx.x % 8;       // 8 lanes per aggregate: 28 * 8 <= 256
+        T s0 = 0, s1 = 0, s2 = 0;
+        if (a < n_agg)
+            for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += 8) {
+                const T* b = P + (size_t)r_to_p[rb] * 9; const size_t i = (size_t)rcol[rb] * 3;
+                const T x0 = res[i], x1 = res[i + 1], x2 = res[i + 2];
+                s0 += b[0] * x0 + b[3] * x1 + b[6] * x2; s1 += b[1] * x0 + b[4] * x1 + b[7] * x2; s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+            }
+        s0 = group_sum<T, 8>(s0); s1 = group_sum<T, 8>(s1); s2 = group_sum<T, 8>(s2);
+        if (a < n_agg && sub == 0) { rc[3 * a] = s0; rc[3 * a + 1] = s1; rc[3 * a + 2] = s2; }
+    }
+    __syncthreads();
+    const int nd = n_agg * 3;
+    if ((int)threadIdx.x < nd) { T s = 0; for (int j = 0; j < nd; ++j) s += inv[(size_t)threadIdx.x * nd + j] * rc[j]; zc_[threadIdx.x] = s; }
+    __syncthreads();
+    const int i = threadIdx.x;
+    if (i < n) {
+        T s0 = 0, s1 = 0, s2 = 0;
+        for (int pb = pptr[i]; pb < pptr[i + 1]; ++pb) {
+            const T* b = P + (size_t)pb * 9; const T* v = zc_ + pcol[pb] * 3;
+            s0 += b[0] * v[0] + b[1] * v[1] + b[2] * v[2]; s1 += b[3] * v[0] + b[4] * v[1] + b[5] * v[2]; s2 += b[6] * v[0] + b[7] * v[1] + b[8] * v[2];
+        }
+        z[(size_t)i * 3] += s0; z[(size_t)i * 3 + 1] += s1; z[(size_t)i * 3 + 2] += s2;
+    }
+}
+
+// coarsest level alone (graphs with a single explicit level): z = inv r, single workgroup
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_dense_apply(int n, const T* __restrict__ inv, const T* __restrict__ r, T* __restrict__ z,
                                                         const CgState<T>* __restrict__ st) {
@@ -291,7 +328,8 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__ sz, const T* __restrict__ dot_part,
                                                     const T* __restrict__ rz_part, int n_part, const CgState<T>* __restrict__ st_in,
                                                     CgState<T>* __restrict__ st_out, T* __restrict__ r, T* __restrict__ p,
-                                                    T* __restrict__ q, T* __restrict__ x, const T* __restrict__ zc, T tol2, int max_iters) {
+                                                    T* __restrict__ q, T* __restrict__ x, T* __restrict__ zc,
+                                                    const T* __restrict__ minv, T tol2, int max_iters) {
     __shared__ T red[kWavesPerBlock];
     const CgState<T> s = *st_in;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
@@ -311,13 +349,19 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
     if (!(alpha > 0) || !(alpha < T(1e300))) { n.done = 1; n.fail = 1; if (writer) *st_out = n; return; }
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i < P) {
+        T rr[3];
 #pragma unroll
         for (int k = 0; k < 3; ++k) {
             const size_t j = (size_t)i * 3 + k;
             const T pk = zc[(size_t)i * kPoseRec + k] + beta * p[j];
             const T qk = sz[j] + beta * q[j];
-            p[j] = pk; q[j] = qk; x[j] += alpha * pk; r[j] -= alpha * qk;
+            p[j] = pk; q[j] = qk; x[j] += alpha * pk; rr[k] = r[j] - alpha * qk; r[j] = rr[k];
         }
+        // level-0 pre-smoothing of the NEXT V-cycle (zero initial guess): zc = Minv r
+        T z0, z1, z2;
+        sym3_mul<T>(minv + (size_t)i * 6, rr[0], rr[1], rr[2], z0, z1, z2);
+        T* zr = zc + (size_t)i * kPoseRec;
+        zr[0] = z0; zr[1] = z1; zr[2] = z2;
     }
     if (writer) { n.gamma_old = gamma; n.alpha_old = alpha; n.iters = s.iters + 1; *st_out = n; }
 }

@@ -251,8 +251,9 @@ template <typename T> struct Engine : IEngine {
         if (int rc = upload_table(tp, pr.by_pose, 4)) return rc;
         if (int rc = upload_table(tl, pr.by_lm, 4)) return rc;
         if (int rc = upload_table(to, pr.odom, 3)) return rc;
-        nbP = (tp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
-        nbL = (tl.n_slices + kWavesPerBlock - 1) / kWavesPerBlock;
+        // table-kernel grids are multiples of 8 (one eighth of the slices per XCD, see xcd_block())
+        nbP = 8 * (((tp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);
+        nbL = 8 * (((tl.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);
         nbC = (P + kBlock - 1) / kBlock;
         if (int rc = dalloc(&part, (size_t)P * 18 + nbP)) return rc;
         if (int rc = dalloc(&dp, (size_t)P * 6)) return rc;
@@ -314,48 +315,70 @@ template <typename T> struct Engine : IEngine {
         hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kBlock), 0, stream, nb_last, last_ptr, last_col, (const T*)A_last, inv_last);
     }
 
-    // zc[.][0..2] = V(1,1)-cycle(r): the preconditioner application of one PCG iteration
+    static int lanes_for(double avg_row) { return avg_row <= 4 ? 4 : (avg_row <= 12 ? 8 : (avg_row <= 40 ? 32 : 64)); }
+#define LAUNCH_LPR(LPR, KERNEL, EXTRA, n_rows, ...)                                                                      \
+    do {                                                                                                                 \
+        switch (LPR) {                                                                                                   \
+            case 4: hipLaunchKernelGGL((KERNEL<T, 4, EXTRA>), dim3(grid_for(n_rows, 4)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
+            case 8: hipLaunchKernelGGL((KERNEL<T, 8, EXTRA>), dim3(grid_for(n_rows, 8)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
+            case 32: hipLaunchKernelGGL((KERNEL<T, 32, EXTRA>), dim3(grid_for(n_rows, 32)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((KERNEL<T, 64, EXTRA>), dim3(grid_for(n_rows, 64)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+        }                                                                                                                \
+    } while (0)
+    void launch_prolong(DevLevel<T>& L, const T* e, T* z, int zs, const CgState<T>* s) {
+        switch (lanes_for((double)L.nnzP / std::max(1, L.n))) {
+            case 4: hipLaunchKernelGGL((k_prolong_add<T, 4>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, z, zs, s); break;
+            case 8: hipLaunchKernelGGL((k_prolong_add<T, 8>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, z, zs, s); break;
+            case 32: hipLaunchKernelGGL((k_prolong_add<T, 32>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, z, zs, s); break;
+            default: hipLaunchKernelGGL((k_prolong_add<T, 64>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, z, zs, s); break;
+        }
+    }
+
+    // zc[.][0..2] = V(1,1)-cycle(r).  On entry zc already holds the level-0 pre-smoothing Minv r
+    // (written by pose_finalize / k_cg_step).  Level l >= 1 keeps r, z (pre-smoothed by the restriction
+    // above it), res and the post-smoothed result z2.
     void launch_vcycle(int slot) {
         const CgState<T>* s = st[slot];
-        const int P = pr.P;
-        const size_t nl = lv.size();
-        hipLaunchKernelGGL((k_smooth0<T, 0>), dim3(nbC), dim3(kBlock), 0, stream, P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, s);
+        const size_t nl = lv.size();              // explicit levels 0 .. nl-1, dense level below
         launch_matvec(slot);
-        {   // restrict r - S z to level 1 (or to the dense level)
+        {
             DevLevel<T>& L = lv[0];
-            T* rc = nl > 1 ? lv[1].r : r_last;
-            hipLaunchKernelGGL((k_restrict<T, 1>), dim3(grid_for(L.n_agg, kLpr)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P,
-                               (const T*)r, (const T*)sbuf, rc, s);
+            const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
+            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P, (const T*)r, (const T*)sbuf, lv[1].r, (const T*)lv[1].Dinv, lv[1].z, s);
         }
         for (size_t l = 1; l < nl; ++l) {
             DevLevel<T>& L = lv[l];
-            T* rc = l + 1 < nl ? lv[l + 1].r : r_last;
-            hipLaunchKernelGGL((k_dinv_apply<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, (const T*)L.Dinv, (const T*)L.r, L.z, s);
-            hipLaunchKernelGGL((k_bcsr_residual<T, 0>), dim3(grid_for(L.n, kLpr)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r,
-                               (const T*)L.z, (const T*)L.Dinv, L.res, s);
-            hipLaunchKernelGGL((k_restrict<T, 0>), dim3(grid_for(L.n_agg, kLpr)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P,
-                               (const T*)L.res, (const T*)L.res, rc, s);
+            const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
+            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)L.z, (const T*)L.Dinv, L.res, s);
+            if (l + 1 < nl) {
+                const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
+                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const T*)lv[l + 1].Dinv, lv[l + 1].z, s);
+            }
         }
-        hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
+        if (nl > 1) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
+            DevLevel<T>& L = lv[nl - 1];
+            hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kBlock), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, L.P_ptr, L.P_col, (const T*)L.P,
+                               (const T*)L.res, (const T*)inv_last, L.z, s);
+        } else {        // only level 0 above the dense level: residual r - S z is restricted from (r, sbuf)
+            DevLevel<T>& L = lv[0];
+            hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P,
+                               (const T*)r, (const T*)sbuf, r_last, (const T*)nullptr, (T*)nullptr, s);
+            hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
+        }
         for (size_t l = nl - 1; l >= 1; --l) {
             DevLevel<T>& L = lv[l];
-            const T* e = l + 1 < nl ? lv[l + 1].z2 : z_last;
-            hipLaunchKernelGGL((k_prolong_add<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, L.z, 3, s);
-            hipLaunchKernelGGL((k_bcsr_residual<T, 1>), dim3(grid_for(L.n, kLpr)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r,
-                               (const T*)L.z, (const T*)L.Dinv, L.z2, s);
+            if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, L.z, 3, s);
+            const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
+            LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)L.z, (const T*)L.Dinv, L.z2, s);
         }
-        {
-            DevLevel<T>& L = lv[0];
-            const T* e = nl > 1 ? lv[1].z2 : z_last;
-            hipLaunchKernelGGL((k_prolong_add<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, zc, kPoseRec, s);
-        }
+        launch_prolong(lv[0], nl > 1 ? (const T*)lv[1].z2 : (const T*)z_last, zc, kPoseRec, s);
         launch_matvec(slot);
-        hipLaunchKernelGGL((k_smooth0<T, 1>), dim3(nbC), dim3(kBlock), 0, stream, P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, s);
+        hipLaunchKernelGGL((k_smooth0<T, 1>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, s);
     }
     void launch_cg_step(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
         hipLaunchKernelGGL((k_cg_step<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)(sbuf + (size_t)pr.P * 3), (const T*)rzpart, nbP,
-                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, (const T*)zc, tol2, cfg.pcg_max_iters);
+                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, tol2, cfg.pcg_max_iters);
     }
     // one PCG iteration reading state slot `slot`, writing slot^1
     void launch_iteration(int slot) {

@@ -39,6 +39,13 @@ template <typename T> struct Table {       // one SELL table on the device
     const uint32_t* row_off; const uint32_t* idx; const T* st; T* dyn; size_t slots; int n_slices; int n_vertices;
 };
 
+// XCD-aware workgroup -> slice-group map (guide T1).  Workgroups are dealt round-robin over the 8 XCDs,
+// each with a private L2; giving XCD x the x-th contiguous eighth of the slices makes every gathered
+// record (pose records, landmark vectors) live in ONE L2 instead of being pulled into all eight
+// (profiles/r01a: 1.7x over-fetch on k_schur_lm).  Grids are rounded up to a multiple of 8; only speed
+// depends on the placement guess, never correctness.
+__device__ __forceinline__ int xcd_block() { return (int)((blockIdx.x % 8u) * (gridDim.x / 8u) + blockIdx.x / 8u); }
+
 template <typename T, int G> __device__ __forceinline__ T group_sum(T v) {
 #pragma unroll
     for (int m = 1; m < G; m <<= 1) v += __shfl_xor(v, m);
@@ -78,7 +85,7 @@ template <typename T> __device__ __forceinline__ T block_sum_array(const T* a, i
 template <typename T, int G>
 __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restrict__ ps, T* __restrict__ lmrec,
                                                    const T* __restrict__ gauge_l) {
-    const int slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int slice = xcd_block() * kWavesPerBlock + (threadIdx.x >> 6);
     if (slice >= tb.n_slices) return;
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;
@@ -122,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
                                                      int pose_first, int pose_last, T* __restrict__ part,
                                                      T* __restrict__ chi_part) {
     __shared__ T red[kWavesPerBlock];
-    const int slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int slice = xcd_block() * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;
@@ -257,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
                                                      T step, T* __restrict__ dl_out, T* __restrict__ norm_part) {
     __shared__ T red[kWavesPerBlock];
     if (MODE == 0 && st->done) return;
-    const int slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int slice = xcd_block() * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;
@@ -309,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
                                                        const T* __restrict__ rvec, T* __restrict__ rz_part) {
     __shared__ T red[kWavesPerBlock];
     if (st->done) return;
-    const int slice = blockIdx.x * kWavesPerBlock + (threadIdx.x >> 6);
+    const int slice = xcd_block() * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;

@@ -9,9 +9,12 @@ A "step" is ONE full Gauss-Newton iteration on the device-resident graph: linear
 configured tolerance, update every vertex.  Inputs are resident in HBM before the timed region
 (tsgo_set_graph is outside it).  value = (ODOM + LM edges) * K / wall time of K steps, max over ranks.
 
-N > 1 shards ONE graph by edge set (strong scaling): landmark ranges per rank, pose state replicated,
-RCCL all-reduce of the pose partials once per GN iteration and of the Schur product once per PCG
-iteration (DESIGN.md, multi-GPU).
+N > 1, default: request-parallel — every rank optimises its OWN graph of the named configuration (seed =
+rank), the way a multi-GPU graph_optimizer serves independent connections; no data-path collective,
+"scaling": "weak".  `--shard` instead splits ONE graph by edge set across the ranks (landmark ranges
+per rank, pose state replicated, RCCL all-reduce of the pose partials once per GN iteration and of the
+Schur product once per PCG iteration; "scaling": "strong"; DESIGN.md section 5 says why that mode is
+latency-bound at this size).
 
 Extra objects on the JSON line: `roofline` (dominant kernel, algorithmic bytes / hipEvent time measured
 here) and `cpu_baseline` (the CPU twin of the same math on the host cores; rank 0, N = 1 only).
@@ -66,12 +69,14 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
 
-    g = synth.make_config(ARGS.workload, seed=0)
+    shard = ARGS.shard and world > 1
+    g = synth.make_config(ARGS.workload, seed=0 if shard else rank)
     n_edges = len(g.e_type)
-    opt = HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol, rank=rank, world=world,
+    opt = HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol,
+                       rank=rank if shard else 0, world=world if shard else 1,
                        use_graphs=not ARGS.no_graphs, lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
                        preconditioner=ARGS.precond)
-    if world > 1:
+    if shard:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
             uid = torch.tensor(list(opt.comm_unique_id()), dtype=torch.uint8, device="cuda")
@@ -99,6 +104,10 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if not shard:           # request-parallel: the job processed every rank's edges
+            e = torch.tensor([float(n_edges)], dtype=torch.float64, device="cuda")
+            dist.all_reduce(e, op=dist.ReduceOp.SUM)
+            n_edges = int(e.item())
     timed_cg = cg[ARGS.warmup:]
 
     out = None
@@ -106,7 +115,7 @@ def main():
         # dominant kernel: the one with the largest share of a GN iteration
         n_cg = float(np.mean(timed_cg)) if timed_cg else 0.0
         shares = {}
-        amg = ARGS.precond == "amg" and world == 1
+        amg = ARGS.precond == "amg" and not shard
         for which in (0, 1, 2, 3, 4):
             us, nbytes = opt.time_kernel(which, reps=200)
             launches = {0: 3.0 if amg else 1.0, 1: 3.0 if amg else 1.0, 2: 0.0 if amg else 1.0}     # per PCG iteration
@@ -118,13 +127,14 @@ def main():
         out = {
             "metric": "edges/sec per GN iter", "value": n_edges * ARGS.steps / dt, "unit": "edges/s",
             "n_gpus": world, "steps": ARGS.steps, "warmup": ARGS.warmup, "ms_per_step": 1e3 * dt / ARGS.steps,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
             "dtype": "f64" if ARGS.precision == 64 else "f32", "data": "synthetic",
             "config": {"workload": "%s: %d poses / %d landmarks / %d ODOM + %d LM edges, seeded synthetic 2-D SLAM graph"
                                    % (ARGS.workload, g.n_poses, g.n_landmarks, int((g.e_type == 0).sum()), int((g.e_type == 1).sum())),
                        "solver": "implicit-Schur PCG (Chronopoulos-Gear), %s, rel tol %g"
-                                 % ("smoothed-aggregation multigrid V(1,1) preconditioner" if (ARGS.precond == "amg" and world == 1) else "block-Jacobi on the Schur diagonal", ARGS.pcg_tol),
-                       "parallelism": "edge-sharded x%d" % world if world > 1 else "single GPU",
+                                 % ("smoothed-aggregation multigrid V(1,1) preconditioner" if (ARGS.precond == "amg" and not shard) else "block-Jacobi on the Schur diagonal", ARGS.pcg_tol),
+                       "parallelism": ("one graph edge-sharded x%d, RCCL all-reduce per PCG iteration" % world) if shard else
+                                      ("request-parallel: %d independent graphs, one per GPU, no collective" % world if world > 1 else "single GPU"),
                        "hipgraph": not ARGS.no_graphs},
             "gn_iters_per_s": ARGS.steps / dt,
             "pcg_iters_per_gn_iter": n_cg,
@@ -155,6 +165,7 @@ if __name__ == "__main__":
     ap.add_argument("--precision", type=int, default=64)
     ap.add_argument("--pcg-tol", dest="pcg_tol", type=float, default=1e-10)
     ap.add_argument("--precond", default="amg", choices=["amg", "jacobi"])
+    ap.add_argument("--shard", action="store_true", help="N > 1: split ONE graph by edge set (strong scaling)")
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true")
     ap.add_argument("--no-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0)

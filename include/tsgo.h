@@ -61,6 +61,7 @@ typedef struct tsgo_config {
     int32_t verbose;
     int32_t preconditioner;  /* 1 (default, single shard): smoothed-aggregation multigrid V-cycle on the reduced
                                 pose system; 0: block-Jacobi on its 3x3 diagonal (always used when world > 1) */
+    int32_t xcd_map;         /* 1: workgroup -> slice map gives each XCD a contiguous eighth of the vertices; 0: round-robin */
 } tsgo_config;
 
 enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_CONVERGED = 3, TSGO_STOP_SOLVER = 4 };

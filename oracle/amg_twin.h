@@ -2,6 +2,7 @@
 // (toyslam_amd/csrc/tsgo_amg_kernels.h), operating on the product's symbolic hierarchy (host/amg.h).
 #pragma once
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -69,7 +70,8 @@ struct Hierarchy {
                     double da[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
                     mat3_mul(&Dinv[l][(size_t)i * 9], acc, da);
                     double* o = &P[l][(size_t)pb * 9];
-                    for (int m = 0; m < 9; ++m) o[m] = -tsgo::kProlongOmega * da[m];
+                    static const double omega = getenv("TSGO_TWIN_OMEGA") ? atof(getenv("TSGO_TWIN_OMEGA")) : tsgo::kProlongOmega;
+                    for (int m = 0; m < 9; ++m) o[m] = -omega * da[m];
                     if (L.p_self[pb]) { o[0] += 1; o[4] += 1; o[8] += 1; o[2] += -L.rel[2 * (size_t)i + 1]; o[5] += L.rel[2 * (size_t)i]; }
                 }
             // T = A P
@@ -161,15 +163,26 @@ struct Hierarchy {
             return;
         }
         const AmgLevel& L = sym->levels[l];
+        static const int nu = getenv("TSGO_TWIN_NU") ? atoi(getenv("TSGO_TWIN_NU")) : 1;       // experiments only
+        static const int gam = getenv("TSGO_TWIN_GAMMA") ? atoi(getenv("TSGO_TWIN_GAMMA")) : 1;
         dinv_apply(Dinv[l], r[l], z[l], L.n, false);
-        spmv(L.A, A[l], z[l], res[l]);
-        for (size_t k = 0; k < res[l].size(); ++k) res[l][k] = r[l][k] - res[l][k];
-        restrict_to(l, res[l], r[l + 1]);
-        cycle(l + 1);
-        prolong_add(l, z[l + 1], z[l]);
-        spmv(L.A, A[l], z[l], res[l]);
-        for (size_t k = 0; k < res[l].size(); ++k) res[l][k] = r[l][k] - res[l][k];
-        dinv_apply(Dinv[l], res[l], z[l], L.n, true);
+        for (int s = 1; s < nu; ++s) {
+            spmv(L.A, A[l], z[l], res[l]);
+            for (size_t k = 0; k < res[l].size(); ++k) res[l][k] = r[l][k] - res[l][k];
+            dinv_apply(Dinv[l], res[l], z[l], L.n, true);
+        }
+        for (int g = 0; g < (l >= 2 ? gam : 1); ++g) {
+            spmv(L.A, A[l], z[l], res[l]);
+            for (size_t k = 0; k < res[l].size(); ++k) res[l][k] = r[l][k] - res[l][k];
+            restrict_to(l, res[l], r[l + 1]);
+            cycle(l + 1);
+            prolong_add(l, z[l + 1], z[l]);
+        }
+        for (int s = 0; s < nu; ++s) {
+            spmv(L.A, A[l], z[l], res[l]);
+            for (size_t k = 0; k < res[l].size(); ++k) res[l][k] = r[l][k] - res[l][k];
+            dinv_apply(Dinv[l], res[l], z[l], L.n, true);
+        }
     }
 };
 

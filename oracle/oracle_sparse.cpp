@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -45,6 +46,7 @@ struct Twin {
     double chi2 = 0;
     std::vector<double> gscratch;
     bool use_amg = false;
+    int n_lin = 0;
     tsgo::AmgSym amg;
     amgtwin::Hierarchy hier;
     std::vector<double> res0, s0;
@@ -131,6 +133,13 @@ struct Twin {
     void amg_apply() {
         for (int i = 0; i < P; ++i) tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
         if (amg.levels.empty()) return;
+        static const bool additive = getenv("TSGO_TWIN_ADDITIVE") != nullptr;
+        if (additive) {
+            hier.restrict_to(0, r, hier.r[1]);
+            hier.cycle(1);
+            hier.prolong_add(0, hier.z[1], z);
+            return;
+        }
         schur_lm(z); schur_pose(z, s0);
         for (size_t k = 0; k < s0.size(); ++k) res0[k] = r[k] - s0[k];
         hier.restrict_to(0, res0, hier.r[1]);
@@ -323,7 +332,9 @@ struct Twin {
         allreduce(part.data(), (int64_t)part.size());
         const double g0 = finalize();
         if (use_amg) {
-            if (!amg.levels.empty()) { build_schur_blocks(); hier.setup_from_level0(); }
+            static const int lag = getenv("TSGO_TWIN_LAG") ? atoi(getenv("TSGO_TWIN_LAG")) : 1;
+            if (!amg.levels.empty() && (n_lin % lag) == 0) { build_schur_blocks(); hier.setup_from_level0(); }
+            ++n_lin;
             amg_apply();
             double g = 0;
             for (int i = 0; i < 3 * P; ++i) g += r[i] * z[i];

@@ -2,6 +2,7 @@
 #include "amg.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <numeric>
 
 namespace tsgo {
@@ -184,8 +185,10 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     std::vector<double> xy((size_t)P * 2);
     for (int i = 0; i < P; ++i) { xy[2 * (size_t)i] = pr.pose_xyt[3 * (size_t)i]; xy[2 * (size_t)i + 1] = pr.pose_xyt[3 * (size_t)i + 1]; }
     L0.agg.resize(P);
-    for (int i = 0; i < P; ++i) L0.agg[i] = S.order[i] / kAggSize;
-    L0.n_agg = (P + kAggSize - 1) / kAggSize;
+    const int agg0 = getenv("TSGO_AGG0") ? atoi(getenv("TSGO_AGG0")) : kAggSize;
+    const int aggc = getenv("TSGO_AGGC") ? atoi(getenv("TSGO_AGGC")) : kAggSize;
+    for (int i = 0; i < P; ++i) L0.agg[i] = S.order[i] / agg0;
+    L0.n_agg = (P + agg0 - 1) / agg0;
     AmgLevel cur = std::move(L0);
     for (;;) {
         if (cur.n <= kCoarsestMax) { S.A_last = cur.A; S.diag_last = find_diag(cur.A); break; }
@@ -196,8 +199,8 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
         cur = AmgLevel();
         cur.n = na; cur.A = std::move(A_next);
         cur.agg.resize(na);
-        for (int a = 0; a < na; ++a) cur.agg[a] = a / kAggSize;     // aggregates are numbered along the trajectory
-        cur.n_agg = (na + kAggSize - 1) / kAggSize;
+        for (int a = 0; a < na; ++a) cur.agg[a] = a / aggc;     // aggregates are numbered along the trajectory
+        cur.n_agg = (na + aggc - 1) / aggc;
         xy = std::move(xy_next);
     }
     out = std::move(S);

@@ -30,10 +30,19 @@ bool invert3(const double* m, double* out) {
 
 namespace {
 
-int auto_lanes(double mean_degree) {
-    if (mean_degree >= 24) return 8;
-    if (mean_degree >= 12) return 4;
+// Lanes per vertex, from the sweep in profiles/r01c (100k poses, MI355X): the landmark passes want ~1-2
+// rows per slice (k_schur_lm 24.1 -> 16.8 us going from 1 to 4 lanes at degree 5); the pose passes carry
+// a longer per-vertex epilogue and the ODOM rows, and are best at 2 lanes for degree 10-12.
+int auto_lanes_pose(double mean_degree) {
+    if (mean_degree >= 40) return 8;
+    if (mean_degree >= 20) return 4;
     if (mean_degree >= 6) return 2;
+    return 1;
+}
+int auto_lanes_lm(double mean_degree) {
+    if (mean_degree >= 16) return 8;
+    if (mean_degree >= 3) return 4;
+    if (mean_degree >= 1.5) return 2;
     return 1;
 }
 
@@ -188,8 +197,8 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
         }
     }
     int Gp = opt.lanes_per_pose, Gl = opt.lanes_per_lm;
-    if (Gp == 0) Gp = auto_lanes(P ? (double)pr.n_lm_edges / P : 0.0);
-    if (Gl == 0) Gl = auto_lanes(L ? (double)pr.n_lm_edges / L : 0.0);
+    if (Gp == 0) Gp = auto_lanes_pose(P ? (double)pr.n_lm_edges / P : 0.0);
+    if (Gl == 0) Gl = auto_lanes_lm(L ? (double)pr.n_lm_edges / L : 0.0);
     if (!valid_lanes(Gp) || !valid_lanes(Gl)) return "lanes per vertex must be 1, 2, 4 or 8";
 
     shape_table(pr.by_pose, Gp, dP, LM_PLANES);

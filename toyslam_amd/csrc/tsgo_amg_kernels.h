@@ -128,34 +128,40 @@ __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __r
     for (int m = 0; m < 9; ++m) P[(size_t)pb * 9 + m] = o[m];
 }
 
-// out[o] = sum over its pair list of X[x] * Y[y]  (TRANS: X[x]^T * Y[y]); one thread per output block.
+// out[o] = sum over its pair list of X[x] * Y[y]  (TRANS: X[x]^T * Y[y]).  Nine lanes per output block,
+// one per element: a lane reads one row of X and one column of Y per pair (the nine lanes of a block
+// touch the same two 72-byte blocks, so the loads coalesce), 7 output blocks per wavefront.
 template <typename T, int TRANS>
 __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __restrict__ ptr, const int* __restrict__ px,
                                                       const int* __restrict__ py, const T* __restrict__ X, const T* __restrict__ Y,
                                                       T* __restrict__ out) {
-    const int o = blockIdx.x * kBlock + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    if (lane >= 63) return;
+    const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    const int o = wave * 7 + lane / 9, e = lane % 9, i = e / 3, j = e % 3;
     if (o >= n_out) return;
-    T acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    T acc = 0;
     for (int q = ptr[o]; q < ptr[o + 1]; ++q) {
-        T a[9], b[9];
-#pragma unroll
-        for (int m = 0; m < 9; ++m) { a[m] = X[(size_t)px[q] * 9 + m]; b[m] = Y[(size_t)py[q] * 9 + m]; }
-        if (TRANS) m3_tmul_acc<T>(a, b, acc); else m3_mul_acc<T>(a, b, acc);
+        const T* a = X + (size_t)px[q] * 9; const T* b = Y + (size_t)py[q] * 9;
+        if (TRANS) acc += a[i] * b[j] + a[3 + i] * b[3 + j] + a[6 + i] * b[6 + j];
+        else acc += a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
     }
-#pragma unroll
-    for (int m = 0; m < 9; ++m) out[(size_t)o * 9 + m] = acc[m];
+    out[(size_t)o * 9 + e] = acc;
 }
 
 // Dense inverse of the coarsest matrix in LDS (n <= 84), in-place Gauss-Jordan; SPD so no pivoting.
+// One workgroup of 1024 threads as a 32 x 32 tile walking the matrix.
+constexpr int kDenseThreads = 1024;
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_dense_inverse(int nb, const int* __restrict__ ptr, const int* __restrict__ col,
-                                                          const T* __restrict__ A, T* __restrict__ inv) {
+__global__ __launch_bounds__(kDenseThreads) void k_dense_inverse(int nb, const int* __restrict__ ptr, const int* __restrict__ col,
+                                                                 const T* __restrict__ A, T* __restrict__ inv) {
     __shared__ T M[kDenseMax * kDenseMax];
     __shared__ T colk[kDenseMax];
     const int n = nb * 3;
-    for (int e = threadIdx.x; e < n * n; e += kBlock) M[e] = T(0);
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int e = threadIdx.x; e < n * n; e += kDenseThreads) M[e] = T(0);
     __syncthreads();
-    for (int i = threadIdx.x; i < nb; i += kBlock)
+    for (int i = threadIdx.x; i < nb; i += kDenseThreads)
         for (int a = ptr[i]; a < ptr[i + 1]; ++a)
             for (int x = 0; x < 3; ++x)
                 for (int y = 0; y < 3; ++y) M[(3 * i + x) * n + 3 * col[a] + y] = A[(size_t)a * 9 + 3 * x + y];
@@ -163,18 +169,18 @@ __global__ __launch_bounds__(kBlock) void k_dense_inverse(int nb, const int* __r
     for (int k = 0; k < n; ++k) {
         const T piv = M[k * n + k];
         const T ip = (fabs(piv) > T(0)) ? T(1) / piv : T(0);
+        if ((int)threadIdx.x < n) colk[threadIdx.x] = M[threadIdx.x * n + k];
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += kBlock) colk[i] = M[i * n + k];
+        if ((int)threadIdx.x < n) M[k * n + threadIdx.x] = ((int)threadIdx.x == k ? T(1) : M[k * n + threadIdx.x]) * ip;
         __syncthreads();
-        for (int j = threadIdx.x; j < n; j += kBlock) M[k * n + j] = (j == k ? T(1) : M[k * n + j]) * ip;
-        __syncthreads();
-        for (int e = threadIdx.x; e < n * n; e += kBlock) {
-            const int i = e / n, j = e - i * n;
-            if (i != k) M[e] = (j == k ? T(0) : M[e]) - colk[i] * M[k * n + j];
+        for (int i = ty; i < n; i += 32) {
+            if (i == k) continue;
+            const T f = colk[i];
+            for (int j = tx; j < n; j += 32) M[i * n + j] = (j == k ? T(0) : M[i * n + j]) - f * M[k * n + j];
         }
         __syncthreads();
     }
-    for (int e = threadIdx.x; e < n * n; e += kBlock) inv[e] = M[e];
+    for (int e = threadIdx.x; e < n * n; e += kDenseThreads) inv[e] = M[e];
 }
 
 // ---- V-cycle ---------------------------------------------------------------------------------------
@@ -256,39 +262,42 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
     if (g < n && sub == 0) { z[(size_t)i * zs] += s0; z[(size_t)i * zs + 1] += s1; z[(size_t)i * zs + 2] += s2; }
 }
 
-// Bottom of the V-cycle in ONE workgroup: restrict the last explicit level's residual (n <= 224 rows)
-// to the dense level (<= 28 aggregates), apply the dense inverse, prolong the correction back.
+// Bottom of the V-cycle in ONE workgroup of 1024 threads: restrict the last explicit level's residual
+// (n <= 224 rows) to the dense level (<= 28 aggregates, 32 lanes each), apply the dense inverse,
+// prolong the correction back (4 lanes per row).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_coarse_tail(int n, int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
-                                                        const int* __restrict__ r_to_p, const int* __restrict__ pptr,
-                                                        const int* __restrict__ pcol, const T* __restrict__ P, const T* __restrict__ res,
-                                                        const T* __restrict__ inv, T* __restrict__ z, const CgState<T>* __restrict__ st) {
+__global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
+                                                               const int* __restrict__ r_to_p, const int* __restrict__ pptr,
+                                                               const int* __restrict__ pcol, const T* __restrict__ P, const T* __restrict__ res,
+                                                               const T* __restrict__ inv, T* __restrict__ z, const CgState<T>* __restrict__ st) {
     if (st->done) return;
     __shared__ T rc[kDenseMax], zc_[kDenseMax];
     {
-        const int a = threadIdx.x / 8, sub = threadIdx.x % 8;       // 8 lanes per aggregate: 28 * 8 <= 256
+        const int a = threadIdx.x / 32, sub = threadIdx.x % 32;
         T s0 = 0, s1 = 0, s2 = 0;
         if (a < n_agg)
-            for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += 8) {
+            for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += 32) {
                 const T* b = P + (size_t)r_to_p[rb] * 9; const size_t i = (size_t)rcol[rb] * 3;
                 const T x0 = res[i], x1 = res[i + 1], x2 = res[i + 2];
                 s0 += b[0] * x0 + b[3] * x1 + b[6] * x2; s1 += b[1] * x0 + b[4] * x1 + b[7] * x2; s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
             }
-        s0 = group_sum<T, 8>(s0); s1 = group_sum<T, 8>(s1); s2 = group_sum<T, 8>(s2);
+        s0 = group_sum<T, 32>(s0); s1 = group_sum<T, 32>(s1); s2 = group_sum<T, 32>(s2);
         if (a < n_agg && sub == 0) { rc[3 * a] = s0; rc[3 * a + 1] = s1; rc[3 * a + 2] = s2; }
     }
     __syncthreads();
     const int nd = n_agg * 3;
     if ((int)threadIdx.x < nd) { T s = 0; for (int j = 0; j < nd; ++j) s += inv[(size_t)threadIdx.x * nd + j] * rc[j]; zc_[threadIdx.x] = s; }
     __syncthreads();
-    const int i = threadIdx.x;
-    if (i < n) {
+    {
+        const int i = threadIdx.x / 4, sub = threadIdx.x % 4;
         T s0 = 0, s1 = 0, s2 = 0;
-        for (int pb = pptr[i]; pb < pptr[i + 1]; ++pb) {
-            const T* b = P + (size_t)pb * 9; const T* v = zc_ + pcol[pb] * 3;
-            s0 += b[0] * v[0] + b[1] * v[1] + b[2] * v[2]; s1 += b[3] * v[0] + b[4] * v[1] + b[5] * v[2]; s2 += b[6] * v[0] + b[7] * v[1] + b[8] * v[2];
-        }
-        z[(size_t)i * 3] += s0; z[(size_t)i * 3 + 1] += s1; z[(size_t)i * 3 + 2] += s2;
+        if (i < n)
+            for (int pb = pptr[i] + sub; pb < pptr[i + 1]; pb += 4) {
+                const T* b = P + (size_t)pb * 9; const T* v = zc_ + pcol[pb] * 3;
+                s0 += b[0] * v[0] + b[1] * v[1] + b[2] * v[2]; s1 += b[3] * v[0] + b[4] * v[1] + b[5] * v[2]; s2 += b[6] * v[0] + b[7] * v[1] + b[8] * v[2];
+            }
+        s0 = group_sum<T, 4>(s0); s1 = group_sum<T, 4>(s1); s2 = group_sum<T, 4>(s2);
+        if (i < n && sub == 0) { z[(size_t)i * 3] += s0; z[(size_t)i * 3 + 1] += s1; z[(size_t)i * 3 + 2] += s2; }
     }
 }
 
@@ -339,7 +348,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
     const T gamma0 = s.iters == 0 ? gamma : s.gamma0;
     CgState<T> n = s; n.gamma0 = gamma0;
     if (!(gamma > tol2 * gamma0) || s.iters >= max_iters) {
-        n.done = 1; n.fail = (gamma != gamma) ? 1 : ((gamma > tol2 * gamma0) ? 2 : 0);
+        // gamma = r^T M^-1 r < 0 (or NaN) means the preconditioner is not positive definite: breakdown,
+        // NOT convergence (the host then repeats the solve with block-Jacobi)
+        n.done = 1; n.fail = (gamma != gamma || gamma < T(0)) ? 1 : ((gamma > tol2 * gamma0) ? 2 : 0);
         if (writer) *st_out = n;
         return;
     }

@@ -214,7 +214,7 @@ template <typename T> struct Engine : IEngine {
     }
 
     int upload_table(Table<T>& t, const SellTable& h, int dyn_planes) {
-        t.slots = h.slots(); t.n_slices = h.n_slices; t.n_vertices = h.n_vertices;
+        t.slots = h.slots(); t.n_slices = h.n_slices; t.n_vertices = h.n_vertices; t.xcd = cfg.xcd_map;
         if (int rc = upload_u32(&t.row_off, h.row_off)) return rc;
         if (int rc = upload_u32(&t.idx, h.idx)) return rc;
         T* stp = nullptr;
@@ -309,10 +309,10 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL((k_block_inv<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.diag, (const T*)L.A, L.Dinv);
             hipLaunchKernelGGL((k_prolongator<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, L.P_row, L.p_self, L.ps_ptr, L.ps_x, L.ps_y,
                                (const T*)L.A, (const T*)L.Dinv, (const T*)L.rel, (T)kProlongOmega, L.P);
-            hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for(L.nnzT)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const T*)L.A, (const T*)L.P, L.Tv);
-            hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for(L.nnzNext)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const T*)L.P, (const T*)L.Tv, Anext);
+            hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for((L.nnzT + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const T*)L.A, (const T*)L.P, L.Tv);
+            hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.nnzNext + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const T*)L.P, (const T*)L.Tv, Anext);
         }
-        hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kBlock), 0, stream, nb_last, last_ptr, last_col, (const T*)A_last, inv_last);
+        hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kDenseThreads), 0, stream, nb_last, last_ptr, last_col, (const T*)A_last, inv_last);
     }
 
     static int lanes_for(double avg_row) { return avg_row <= 4 ? 4 : (avg_row <= 12 ? 8 : (avg_row <= 40 ? 32 : 64)); }
@@ -357,7 +357,7 @@ template <typename T> struct Engine : IEngine {
         }
         if (nl > 1) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
             DevLevel<T>& L = lv[nl - 1];
-            hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kBlock), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, L.P_ptr, L.P_col, (const T*)L.P,
+            hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kDenseThreads), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, L.P_ptr, L.P_col, (const T*)L.P,
                                (const T*)L.res, (const T*)inv_last, L.z, s);
         } else {        // only level 0 above the dense level: residual r - S z is restricted from (r, sbuf)
             DevLevel<T>& L = lv[0];
@@ -421,8 +421,24 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
 
-    // PCG until the device state says done.  The state ring is at slot 0 on entry and on exit.
+    // PCG; if the multigrid-preconditioned solve breaks down (indefinite preconditioner), the solve is
+    // repeated from the same right-hand side with the block-Jacobi preconditioner.
+    int n_fallbacks = 0;
     int do_solve(int* iters, int* fail) {
+        if (int rc = do_solve_once(iters, fail)) return rc;
+        if (*fail == 1 && amg_on) {
+            ++n_fallbacks;
+            const bool keep = amg_on; hipGraphExec_t g = cg_graph;
+            amg_on = false; cg_graph = nullptr;          // eager block-Jacobi launches
+            launch_finalize();
+            const int rc = do_solve_once(iters, fail);
+            amg_on = keep; cg_graph = g;
+            return rc;
+        }
+        return 0;
+    }
+    // PCG until the device state says done.  The state ring is at slot 0 on entry and on exit.
+    int do_solve_once(int* iters, int* fail) {
         int launched = 0;
         const int ch = chunk();
         int burst = std::max(1, (int)(0.9 * predicted_cg) / ch);    // chunks before the first look

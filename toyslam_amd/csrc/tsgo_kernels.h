@@ -36,7 +36,7 @@ constexpr int kLmRec = 8;     // lmrec: lx ly ixx ixy iyy ux uy .   (landmark, D
 template <typename T> struct CgState { T gamma_old, alpha_old, gamma0, pad; int iters, done, fail, pad2; };
 
 template <typename T> struct Table {       // one SELL table on the device
-    const uint32_t* row_off; const uint32_t* idx; const T* st; T* dyn; size_t slots; int n_slices; int n_vertices;
+    const uint32_t* row_off; const uint32_t* idx; const T* st; T* dyn; size_t slots; int n_slices; int n_vertices; int xcd;
 };
 
 // XCD-aware workgroup -> slice-group map (guide T1).  Workgroups are dealt round-robin over the 8 XCDs,
@@ -85,7 +85,7 @@ template <typename T> __device__ __forceinline__ T block_sum_array(const T* a, i
 template <typename T, int G>
 __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restrict__ ps, T* __restrict__ lmrec,
                                                    const T* __restrict__ gauge_l) {
-    const int slice = xcd_block() * kWavesPerBlock + (threadIdx.x >> 6);
+    const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (slice >= tb.n_slices) return;
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;
@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
                                                      int pose_first, int pose_last, T* __restrict__ part,
                                                      T* __restrict__ chi_part) {
     __shared__ T red[kWavesPerBlock];
-    const int slice = xcd_block() * kWavesPerBlock + (threadIdx.x >> 6);
+    const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;
@@ -264,7 +264,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
                                                      T step, T* __restrict__ dl_out, T* __restrict__ norm_part) {
     __shared__ T red[kWavesPerBlock];
     if (MODE == 0 && st->done) return;
-    const int slice = xcd_block() * kWavesPerBlock + (threadIdx.x >> 6);
+    const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;
@@ -316,7 +316,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
                                                        const T* __restrict__ rvec, T* __restrict__ rz_part) {
     __shared__ T red[kWavesPerBlock];
     if (st->done) return;
-    const int slice = xcd_block() * kWavesPerBlock + (threadIdx.x >> 6);
+    const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;

@@ -33,6 +33,15 @@ constexpr uint32_t kDirMask = 0x80000000u;
 constexpr int kPoseRec = 8;   // zc: v0 v1 v2 c s . . .      (the vector CG multiplies + the pose's cos/sin)
 constexpr int kLmRec = 8;     // lmrec: lx ly ixx ixy iyy ux uy .   (landmark, Dl^-1, u = Dl^-1 g_l)
 
+// 16-byte (f64) / 8-byte (f32) pair loads for the gathered records: one gathered 64-B pose record costs
+// three load instructions instead of five (each wave-instruction of a gather touches 64 lines).
+template <typename T> struct Pair;
+template <> struct Pair<double> { using type = double2; };
+template <> struct Pair<float> { using type = float2; };
+template <typename T> __device__ __forceinline__ typename Pair<T>::type ld2(const T* p) {
+    return *reinterpret_cast<const typename Pair<T>::type*>(p);
+}
+
 template <typename T> struct CgState { T gamma_old, alpha_old, gamma0, pad; int iters, done, fail, pad2; };
 
 template <typename T> struct Table {       // one SELL table on the device
@@ -101,7 +110,8 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restr
         const uint32_t i = tb.idx[k];
         const T zx = tb.st[k], zy = tb.st[S + k], w0 = tb.st[2 * S + k], w1 = tb.st[3 * S + k];
         const T* q = ps + (size_t)i * 4;
-        const T x = q[0], y = q[1], c = q[2], s = q[3];
+        const auto q01 = ld2<T>(q), q23 = ld2<T>(q + 2);
+        const T x = q01.x, y = q01.y, c = q23.x, s = q23.y;
         const LmLin<T> o = lm_linearize<T>(x, y, c, s, lx, ly, zx, zy, w0, w1);
         tb.dyn[k] = o.a0; tb.dyn[S + k] = o.a1; tb.dyn[2 * S + k] = o.ppx; tb.dyn[3 * S + k] = o.ppy;
         dxx += o.a0 * c * c + o.a1 * s * s; dxy += (o.a0 - o.a1) * c * s; dyy += o.a0 * s * s + o.a1 * c * c;
@@ -149,7 +159,8 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
                 const uint32_t l = tb.idx[k];
                 const T zx = tb.st[k], zy = tb.st[S + k], w0 = tb.st[2 * S + k], w1 = tb.st[3 * S + k];
                 const T* lr = lmrec + (size_t)l * kLmRec;
-                const T lx = lr[0], ly = lr[1], nxx = lr[2], nxy = lr[3], nyy = lr[4], ux = lr[5], uy = lr[6];
+                const auto l01 = ld2<T>(lr), l23 = ld2<T>(lr + 2), l45 = ld2<T>(lr + 4);
+                const T lx = l01.x, ly = l01.y, nxx = l23.x, nxy = l23.y, nyy = l45.x, ux = l45.y, uy = lr[6];
                 const LmLin<T> o = lm_linearize<T>(x0, y0, c, s, lx, ly, zx, zy, w0, w1);
                 tb.dyn[k] = o.a0; tb.dyn[S + k] = o.a1; tb.dyn[2 * S + k] = o.ppx; tb.dyn[3 * S + k] = o.ppy;
                 chi += o.rho;
@@ -280,7 +291,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
             const uint32_t i = tb.idx[k];
             const T a0 = tb.dyn[k], a1 = tb.dyn[S + k], ppx = tb.dyn[2 * S + k], ppy = tb.dyn[3 * S + k];
             const T* zr = zc + (size_t)i * kPoseRec;
-            const T v0 = zr[0], v1 = zr[1], v2 = zr[2], c = zr[3], s = zr[4];
+            const auto z01 = ld2<T>(zr), z23 = ld2<T>(zr + 2);
+            const T v0 = z01.x, v1 = z01.y, v2 = z23.x, c = z23.y, s = zr[4];
             const T vt0 = c * v0 + s * v1, vt1 = c * v1 - s * v0;
             const T m0 = a0 * (ppy * v2 - vt0), m1 = a1 * (-vt1 - ppx * v2);
             acc0 += c * m0 - s * m1; acc1 += s * m0 + c * m1;
@@ -336,7 +348,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
                 const size_t k = (size_t)row * 64 + lane;
                 const uint32_t l = tb.idx[k];
                 const T a0 = tb.dyn[k], a1 = tb.dyn[S + k], ppx = tb.dyn[2 * S + k], ppy = tb.dyn[3 * S + k];
-                const T tx = t[(size_t)l * 2], ty = t[(size_t)l * 2 + 1];
+                const auto txy = ld2<T>(t + (size_t)l * 2);
+                const T tx = txy.x, ty = txy.y;
                 const T t0 = a0 * (c * tx + s * ty), t1 = a1 * (c * ty - s * tx);
                 acc0 += t0; acc1 += t1; acc2 += t0 * ppy - t1 * ppx;
             }

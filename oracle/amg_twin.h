@@ -163,7 +163,7 @@ struct Hierarchy {
             return;
         }
         const AmgLevel& L = sym->levels[l];
-        static const int nu = getenv("TSGO_TWIN_NU") ? atoi(getenv("TSGO_TWIN_NU")) : 1;       // experiments only
+        static const int nu = getenv("TSGO_TWIN_NU") ? atoi(getenv("TSGO_TWIN_NU")) : tsgo::kCoarseSweeps;
         static const int gam = getenv("TSGO_TWIN_GAMMA") ? atoi(getenv("TSGO_TWIN_GAMMA")) : 1;
         dinv_apply(Dinv[l], r[l], z[l], L.n, false);
         for (int s = 1; s < nu; ++s) {

@@ -32,7 +32,7 @@ def hipcc():
 
 def build_host(force=False):
     if force or _newer(HOST_SO, _all_sources()):
-        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-shared", "-o", HOST_SO] + HOST_SRC
+        cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-Wall", "-pthread", "-shared", "-o", HOST_SO] + HOST_SRC
         subprocess.check_call(cmd, cwd=CSRC)
     return HOST_SO
 
@@ -40,7 +40,7 @@ def build_host(force=False):
 def build_hip(force=False):
     if force or _newer(HIP_SO, _all_sources()):
         cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result",
-               "-o", HIP_SO, "tsgo_hip.hip"] + HOST_SRC + ["-lrccl"]
+               "-o", HIP_SO, "tsgo_hip.hip"] + HOST_SRC + ["-lrccl", "-lpthread"]
         subprocess.check_call(cmd, cwd=CSRC)
     return HIP_SO
 

@@ -1,9 +1,14 @@
 // amg.cpp — host-side symbolic setup of the smoothed-aggregation hierarchy (see amg.h).
 #include "amg.h"
 
+#include <sched.h>
+
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
+#include <thread>
 
 namespace tsgo {
 namespace {
@@ -17,30 +22,95 @@ template <typename F> void for_slots(const SellTable& tb, int v, F f) {
         }
 }
 
+struct Stopwatch {
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    bool on = getenv("TSGO_AMG_TIMING") != nullptr;
+    void lap(const char* what) {
+        auto n = std::chrono::steady_clock::now();
+        if (on) std::fprintf(stderr, "[amg symbolic] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
+
 struct Triple { int c, x, y; };
+inline bool triple_less(const Triple& p, const Triple& q) { return p.c != q.c ? p.c < q.c : (p.x != q.x ? p.x < q.x : p.y < q.y); }
+
+int host_threads() {
+    if (const char* e = getenv("TSGO_HOST_THREADS")) return std::max(1, atoi(e));
+    cpu_set_t set; CPU_ZERO(&set);
+    int n = 0;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    if (n <= 0) n = (int)std::thread::hardware_concurrency();
+    return std::max(1, std::min(8, n / 2));      // half the logical CPUs: page-fault and allocator locks stop scaling past that
+}
+
+// f(chunk, begin, end) over [0, n) split into contiguous chunks, one std::thread each.
+template <typename F> int parallel_chunks(int n, F f) {
+    const int nt = std::max(1, std::min(host_threads(), n / 8));
+    if (nt == 1) { f(0, 0, n); return 1; }
+    std::vector<std::thread> th;
+    for (int c = 0; c < nt; ++c) {
+        const int b = (int)((int64_t)n * c / nt), e = (int)((int64_t)n * (c + 1) / nt);
+        th.emplace_back([=, &f] { f(c, b, e); });
+    }
+    for (auto& t : th) t.join();
+    return nt;
+}
+
+template <typename V> void append(std::vector<V>& dst, const std::vector<V>& src) { dst.insert(dst.end(), src.begin(), src.end()); }
+
+// Row-wise grouped output of a symbolic product, built per chunk and concatenated in row order.
+struct RowsOut {
+    std::vector<int> row_nnz, col, grp_len, x, y, flag;
+};
+void concat(std::vector<RowsOut>& parts, int used, BlockCsr& Z, PairList& pl, std::vector<int>* flag) {
+    Z.ptr.assign(1, 0); Z.col.clear(); pl.ptr.assign(1, 0); pl.x.clear(); pl.y.clear();
+    if (flag) flag->clear();
+    size_t ncol = 0, npair = 0;
+    for (int c = 0; c < used; ++c) { ncol += parts[c].col.size(); npair += parts[c].x.size(); }
+    Z.col.reserve(ncol); pl.ptr.reserve(ncol + 1); pl.x.reserve(npair); pl.y.reserve(npair);
+    for (int c = 0; c < used; ++c) {
+        RowsOut& p = parts[c];
+        for (int nn : p.row_nnz) Z.ptr.push_back(Z.ptr.back() + nn);
+        append(Z.col, p.col);
+        for (int g : p.grp_len) pl.ptr.push_back(pl.ptr.back() + g);
+        append(pl.x, p.x); append(pl.y, p.y);
+        if (flag) append(*flag, p.flag);
+        p = RowsOut();
+    }
+}
+// sorted triples of one row -> grouped output
+inline void emit_row(std::vector<Triple>& row, RowsOut& o) {
+    std::sort(row.begin(), row.end(), triple_less);
+    int nn = 0;
+    for (size_t t = 0; t < row.size(); ++t) {
+        if (t == 0 || row[t].c != row[t - 1].c) { o.col.push_back(row[t].c); o.grp_len.push_back(0); ++nn; }
+        if (row[t].x >= 0) { o.x.push_back(row[t].x); o.y.push_back(row[t].y); ++o.grp_len.back(); }
+    }
+    o.row_nnz.push_back(nn);
+}
 
 // Z = X * Y (patterns), with the (x block, y block) pairs that sum into every Z block, row by row.
 void spgemm_sym(const BlockCsr& X, const std::vector<int>* x_alias, const BlockCsr& Y, BlockCsr& Z, PairList& pl) {
-    Z.n_rows = X.n_rows; Z.n_cols = Y.n_cols; Z.ptr.assign(1, 0); Z.col.clear();
-    pl.ptr.assign(1, 0); pl.x.clear(); pl.y.clear();
-    std::vector<Triple> row;
-    for (int i = 0; i < X.n_rows; ++i) {
-        row.clear();
-        for (int a = X.ptr[i]; a < X.ptr[i + 1]; ++a) {
-            const int k = X.col[a];
-            for (int b = Y.ptr[k]; b < Y.ptr[k + 1]; ++b) row.push_back({Y.col[b], x_alias ? (*x_alias)[a] : a, b});
-        }
-        std::stable_sort(row.begin(), row.end(), [](const Triple& p, const Triple& q) { return p.c < q.c; });
-        for (size_t t = 0; t < row.size(); ++t) {
-            if (t == 0 || row[t].c != row[t - 1].c) {
-                if (t) pl.ptr.push_back((int)pl.x.size());
-                Z.col.push_back(row[t].c);
+    Z.n_rows = X.n_rows; Z.n_cols = Y.n_cols;
+    const auto t_begin = std::chrono::steady_clock::now();
+    std::vector<RowsOut> parts(64);
+    const int used = parallel_chunks(X.n_rows, [&](int c, int b, int e) {
+        std::vector<Triple> row;
+        RowsOut o;                       // thread-local: adjacent vector headers in `parts` would false-share
+        for (int i = b; i < e; ++i) {
+            row.clear();
+            for (int a = X.ptr[i]; a < X.ptr[i + 1]; ++a) {
+                const int k = X.col[a];
+                for (int q = Y.ptr[k]; q < Y.ptr[k + 1]; ++q) row.push_back({Y.col[q], x_alias ? (*x_alias)[a] : a, q});
             }
-            pl.x.push_back(row[t].x); pl.y.push_back(row[t].y);
+            emit_row(row, o);
         }
-        if (!row.empty()) pl.ptr.push_back((int)pl.x.size());
-        Z.ptr.push_back((int)Z.col.size());
-    }
+        parts[c] = std::move(o);
+    });
+    Stopwatch sw3; sw3.t = t_begin; sw3.lap("    spgemm parallel part");
+    concat(parts, used, Z, pl, nullptr);
+    sw3.lap("    spgemm concat");
 }
 
 void transpose_pattern(const BlockCsr& X, BlockCsr& Xt, std::vector<int>& to_src) {
@@ -74,34 +144,40 @@ void coarsen(AmgLevel& L, const std::vector<double>& xy, BlockCsr& A_next, std::
     L.rel.resize((size_t)n * 2);
     for (int i = 0; i < n; ++i) { L.rel[2 * (size_t)i] = xy[2 * (size_t)i] - xy_next[2 * (size_t)L.agg[i]]; L.rel[2 * (size_t)i + 1] = xy[2 * (size_t)i + 1] - xy_next[2 * (size_t)L.agg[i] + 1]; }
     // P pattern: aggregates of the row's neighbours
-    L.P.n_rows = n; L.P.n_cols = na; L.P.ptr.assign(1, 0); L.P.col.clear(); L.p_self.clear();
-    L.p_src.ptr.assign(1, 0); L.p_src.x.clear(); L.p_src.y.clear();
-    std::vector<Triple> row;
-    for (int i = 0; i < n; ++i) {
-        row.clear();
-        bool has_self = false;
-        for (int a = L.A.ptr[i]; a < L.A.ptr[i + 1]; ++a) { row.push_back({L.agg[L.A.col[a]], a, L.A.col[a]}); has_self |= L.agg[L.A.col[a]] == L.agg[i]; }
-        if (!has_self) row.push_back({L.agg[i], -1, -1});      // structurally missing diagonal
-        std::stable_sort(row.begin(), row.end(), [](const Triple& p, const Triple& q) { return p.c < q.c; });
-        for (size_t t = 0; t < row.size(); ++t) {
-            if (t == 0 || row[t].c != row[t - 1].c) {
-                if (t) L.p_src.ptr.push_back((int)L.p_src.x.size());
-                L.P.col.push_back(row[t].c); L.p_self.push_back(row[t].c == L.agg[i] ? 1 : 0);
+    L.P.n_rows = n; L.P.n_cols = na;
+    {
+        std::vector<RowsOut> parts(64);
+        const int used = parallel_chunks(n, [&](int c, int b, int e) {
+            std::vector<Triple> row;
+            RowsOut o;
+            for (int i = b; i < e; ++i) {
+                row.clear();
+                bool has_self = false;
+                for (int a = L.A.ptr[i]; a < L.A.ptr[i + 1]; ++a) { row.push_back({L.agg[L.A.col[a]], a, L.A.col[a]}); has_self |= L.agg[L.A.col[a]] == L.agg[i]; }
+                if (!has_self) row.push_back({L.agg[i], -1, -1});      // structurally missing diagonal
+                const size_t before = o.col.size();
+                emit_row(row, o);
+                for (size_t t = before; t < o.col.size(); ++t) o.flag.push_back(o.col[t] == L.agg[i] ? 1 : 0);
             }
-            if (row[t].x >= 0) { L.p_src.x.push_back(row[t].x); L.p_src.y.push_back(row[t].y); }
-        }
-        L.p_src.ptr.push_back((int)L.p_src.x.size());
-        L.P.ptr.push_back((int)L.P.col.size());
+            parts[c] = std::move(o);
+        });
+        concat(parts, used, L.P, L.p_src, &L.p_self);
     }
+    Stopwatch sw2;
+    sw2.lap("  (P pattern)");
     transpose_pattern(L.P, L.R, L.r_to_p);
+    sw2.lap("  transpose");
     spgemm_sym(L.A, nullptr, L.P, L.T, L.t_src);
+    sw2.lap("  T = A P");
     spgemm_sym(L.R, &L.r_to_p, L.T, A_next, L.a_src);
+    sw2.lap("  A' = R T");
 }
 
 }  // namespace
 
 std::string build_amg(const Problem& pr, AmgSym& out) {
     if (pr.world != 1) return "the multigrid preconditioner is single-shard";
+    Stopwatch sw;
     AmgSym S;
     const int P = pr.P;
     // ---- trajectory order: follow ODOM edges id1 -> id2 where that is a simple chain ------------------
@@ -125,61 +201,71 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
         for (int v : by_vertex) if (indeg[v] == 0) walk(v);   // chain heads, in input order
         for (int v : by_vertex) walk(v);                      // cycles / leftovers
     }
+    sw.lap("trajectory order");
     // ---- level 0: pattern of S and the contribution lists --------------------------------------------
     uint32_t max_edge = 0;
     for (uint32_t e : pr.by_pose.edge) if (e != kNoEdge) max_edge = std::max(max_edge, e);
     std::vector<uint32_t> epos((size_t)max_edge + 1, 0);
     for (size_t s = 0; s < pr.by_pose.edge.size(); ++s) if (pr.by_pose.edge[s] != kNoEdge) epos[pr.by_pose.edge[s]] = (uint32_t)s;
-
-    struct Tup { int i, k; uint32_t a, b; int kind; };          // kind 0: landmark pair, 1: odom slot
-    std::vector<int> row_count(P + 1, 0);
-    std::vector<Tup> tup;
-    {
-        std::vector<std::pair<int, uint32_t>> obs;
-        for (int l = 0; l < pr.L; ++l) {
-            obs.clear();
-            for_slots(pr.by_lm, l, [&](size_t k) { obs.emplace_back((int)pr.by_lm.idx[k], epos[pr.by_lm.edge[k]]); });
-            for (size_t x = 0; x < obs.size(); ++x)
-                for (size_t y = 0; y < obs.size(); ++y)
-                    if (obs[x].first != obs[y].first) tup.push_back({obs[x].first, obs[y].first, obs[x].second, obs[y].second, 0});
-        }
-        for (int i = 0; i < P; ++i)
-            for_slots(pr.odom, i, [&](size_t k) {
-                const int j = (int)(pr.odom.idx[k] & ~kDirBit);
-                if (j != i) tup.push_back({i, j, (uint32_t)k, 0u, 1});
-            });
+    // observers of every landmark: (pose, by_pose slot of that edge)
+    std::vector<int> obs_ptr(pr.L + 1, 0);
+    std::vector<int> obs_pose; std::vector<uint32_t> obs_slot;
+    for (int l = 0; l < pr.L; ++l) {
+        for_slots(pr.by_lm, l, [&](size_t k) { obs_pose.push_back((int)pr.by_lm.idx[k]); obs_slot.push_back(epos[pr.by_lm.edge[k]]); });
+        obs_ptr[l + 1] = (int)obs_pose.size();
     }
-    for (const Tup& t : tup) ++row_count[t.i + 1];
-    for (int i = 0; i < P; ++i) row_count[i + 1] += row_count[i];
-    std::vector<Tup> sorted(tup.size());
-    {
-        std::vector<int> cur(row_count.begin(), row_count.end() - 1);
-        for (const Tup& t : tup) sorted[cur[t.i]++] = t;
-    }
-    tup.clear(); tup.shrink_to_fit();
+    sw.lap("landmark observers");
+    struct Tup { int k; uint32_t a, b; int kind; };            // kind 0: landmark pair, 1: odom slot
+    struct SOut { std::vector<int> row_nnz, col, n_pair, n_od; std::vector<uint32_t> si, sk, os; };
     AmgLevel L0;
     L0.n = P;
-    L0.A.n_rows = L0.A.n_cols = P; L0.A.ptr.assign(1, 0);
-    S.schur.ptr.assign(1, 0); S.schur.od_ptr.assign(1, 0);
-    for (int i = 0; i < P; ++i) {
-        auto b = sorted.begin() + row_count[i], e = sorted.begin() + row_count[i + 1];
-        std::stable_sort(b, e, [](const Tup& p, const Tup& q) { return p.k < q.k; });
-        bool diag_done = false;
-        auto emit_diag = [&] { L0.A.col.push_back(i); S.schur.ptr.push_back((int)S.schur.slot_i.size()); S.schur.od_ptr.push_back((int)S.schur.od_slot.size()); diag_done = true; };
-        for (auto it = b; it != e;) {
-            const int k = it->k;
-            if (!diag_done && k > i) emit_diag();
-            L0.A.col.push_back(k);
-            for (; it != e && it->k == k; ++it) {
-                if (it->kind == 0) { S.schur.slot_i.push_back(it->a); S.schur.slot_k.push_back(it->b); }
-                else S.schur.od_slot.push_back(it->a);
+    L0.A.n_rows = L0.A.n_cols = P;
+    {
+        std::vector<SOut> parts(64);
+        const int used = parallel_chunks(P, [&](int c, int b, int e) {
+            std::vector<Tup> row;
+            SOut o;
+            for (int i = b; i < e; ++i) {
+                row.clear();
+                for_slots(pr.by_pose, i, [&](size_t k) {
+                    const int l = (int)pr.by_pose.idx[k];
+                    for (int q = obs_ptr[l]; q < obs_ptr[l + 1]; ++q)
+                        if (obs_pose[q] != i) row.push_back({obs_pose[q], (uint32_t)k, obs_slot[q], 0});
+                });
+                for_slots(pr.odom, i, [&](size_t k) {
+                    const int j = (int)(pr.odom.idx[k] & ~kDirBit);
+                    if (j != i) row.push_back({j, (uint32_t)k, 0u, 1});
+                });
+                std::sort(row.begin(), row.end(), [](const Tup& p, const Tup& q) {
+                    return p.k != q.k ? p.k < q.k : (p.kind != q.kind ? p.kind < q.kind : (p.a != q.a ? p.a < q.a : p.b < q.b)); });
+                int nn = 0; bool diag_done = false;
+                auto emit_diag = [&] { o.col.push_back(i); o.n_pair.push_back(0); o.n_od.push_back(0); diag_done = true; ++nn; };
+                for (size_t t = 0; t < row.size();) {
+                    const int k = row[t].k;
+                    if (!diag_done && k > i) emit_diag();
+                    o.col.push_back(k); o.n_pair.push_back(0); o.n_od.push_back(0); ++nn;
+                    for (; t < row.size() && row[t].k == k; ++t) {
+                        if (row[t].kind == 0) { o.si.push_back(row[t].a); o.sk.push_back(row[t].b); ++o.n_pair.back(); }
+                        else { o.os.push_back(row[t].a); ++o.n_od.back(); }
+                    }
+                }
+                if (!diag_done) emit_diag();
+                o.row_nnz.push_back(nn);
             }
-            S.schur.ptr.push_back((int)S.schur.slot_i.size()); S.schur.od_ptr.push_back((int)S.schur.od_slot.size());
+            parts[c] = std::move(o);
+        });
+        L0.A.ptr.assign(1, 0); S.schur.ptr.assign(1, 0); S.schur.od_ptr.assign(1, 0);
+        for (int c = 0; c < used; ++c) {
+            SOut& o = parts[c];
+            for (int nn : o.row_nnz) L0.A.ptr.push_back(L0.A.ptr.back() + nn);
+            append(L0.A.col, o.col);
+            for (int g : o.n_pair) S.schur.ptr.push_back(S.schur.ptr.back() + g);
+            for (int g : o.n_od) S.schur.od_ptr.push_back(S.schur.od_ptr.back() + g);
+            append(S.schur.slot_i, o.si); append(S.schur.slot_k, o.sk); append(S.schur.od_slot, o.os);
+            o = SOut();
         }
-        if (!diag_done) emit_diag();
-        L0.A.ptr.push_back((int)L0.A.col.size());
     }
-    sorted.clear(); sorted.shrink_to_fit();
+    sw.lap("S pattern + lists");
 
     // ---- hierarchy ----------------------------------------------------------------------------------------
     std::vector<double> xy((size_t)P * 2);
@@ -194,6 +280,7 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
         if (cur.n <= kCoarsestMax) { S.A_last = cur.A; S.diag_last = find_diag(cur.A); break; }
         BlockCsr A_next; std::vector<double> xy_next;
         coarsen(cur, xy, A_next, xy_next);
+        sw.lap("coarsen level");
         const int na = cur.n_agg;
         S.levels.push_back(std::move(cur));
         cur = AmgLevel();

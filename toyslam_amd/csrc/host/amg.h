@@ -23,6 +23,8 @@ namespace tsgo {
 constexpr int kAggSize = 8;          // nodes per aggregate
 constexpr int kCoarsestMax = 28;     // stop coarsening at <= this many block rows (dense inverse in LDS, <= 84 x 84)
 constexpr double kProlongOmega = 0.7;
+constexpr int kCoarseSweeps = 2;      // block-Jacobi sweeps per side on the coarse levels: V(1,1) on level 0, V(2,2) below
+                                      // (100k poses: 66 -> 53 PCG iterations for +30 us per iteration)
 
 struct BlockCsr {
     int n_rows = 0, n_cols = 0;

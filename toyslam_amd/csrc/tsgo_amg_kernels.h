@@ -103,7 +103,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __restrict__ p_row, const int* __restrict__ p_self,
                                                         const int* __restrict__ sptr, const int* __restrict__ sx, const int* __restrict__ sy,
                                                         const T* __restrict__ A, const T* __restrict__ Dinv, const T* __restrict__ rel,
-                                                        T omega, T* __restrict__ P) {
+                                                        T omega, T* __restrict__ P, const int* __restrict__ p_to_r, T* __restrict__ Rv) {
     const int pb = blockIdx.x * kBlock + threadIdx.x;
     if (pb >= nnzP) return;
     const int i = p_row[pb];
@@ -126,6 +126,13 @@ __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __r
     if (p_self[pb]) { o[0] += T(1); o[4] += T(1); o[8] += T(1); o[2] -= rel[(size_t)i * 2 + 1]; o[5] += rel[(size_t)i * 2]; }
 #pragma unroll
     for (int m = 0; m < 9; ++m) P[(size_t)pb * 9 + m] = o[m];
+    // the same block transposed, stored in the order the restriction walks it (rows of R = P^T):
+    // reading P through an index there cost 2.7x the bytes (profiles/r01c: 88 MB for a 33 MB operator)
+    T* rt = Rv + (size_t)p_to_r[pb] * 9;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) rt[3 * i + j] = o[3 * j + i];
 }
 
 // out[o] = sum over its pair list of X[x] * Y[y]  (TRANS: X[x]^T * Y[y]).  Nine lanes per output block,
@@ -220,7 +227,7 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
 // z_next = Dinv_next rc in the same pass.  SUB: v = a - b (level 0: r - S z, never materialised).
 template <typename T, int LPR, int SUB>
 __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
-                                                     const int* __restrict__ r_to_p, const T* __restrict__ P, const T* __restrict__ va,
+                                                     const T* __restrict__ Rv, const T* __restrict__ va,
                                                      const T* __restrict__ vb, T* __restrict__ rc, const T* __restrict__ dinv_next,
                                                      T* __restrict__ z_next, const CgState<T>* __restrict__ st) {
     if (st->done) return;
@@ -228,10 +235,10 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
     const int a = g < n_agg ? g : n_agg - 1;
     T s0 = 0, s1 = 0, s2 = 0;
     for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += LPR) {
-        const T* b = P + (size_t)r_to_p[rb] * 9; const size_t i = (size_t)rcol[rb] * 3;
+        const T* b = Rv + (size_t)rb * 9; const size_t i = (size_t)rcol[rb] * 3;
         T x0 = va[i], x1 = va[i + 1], x2 = va[i + 2];
         if (SUB) { x0 -= vb[i]; x1 -= vb[i + 1]; x2 -= vb[i + 2]; }
-        s0 += b[0] * x0 + b[3] * x1 + b[6] * x2; s1 += b[1] * x0 + b[4] * x1 + b[7] * x2; s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+        s0 += b[0] * x0 + b[1] * x1 + b[2] * x2; s1 += b[3] * x0 + b[4] * x1 + b[5] * x2; s2 += b[6] * x0 + b[7] * x1 + b[8] * x2;
     }
     s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
     if (g < n_agg && sub == 0) {
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
 // prolong the correction back (4 lanes per row).
 template <typename T>
 __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
-                                                               const int* __restrict__ r_to_p, const int* __restrict__ pptr,
+                                                               const T* __restrict__ Rv, const int* __restrict__ pptr,
                                                                const int* __restrict__ pcol, const T* __restrict__ P, const T* __restrict__ res,
                                                                const T* __restrict__ inv, T* __restrict__ z, const CgState<T>* __restrict__ st) {
     if (st->done) return;
@@ -277,9 +284,9 @@ __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg,
         T s0 = 0, s1 = 0, s2 = 0;
         if (a < n_agg)
             for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += 32) {
-                const T* b = P + (size_t)r_to_p[rb] * 9; const size_t i = (size_t)rcol[rb] * 3;
+                const T* b = Rv + (size_t)rb * 9; const size_t i = (size_t)rcol[rb] * 3;
                 const T x0 = res[i], x1 = res[i + 1], x2 = res[i + 2];
-                s0 += b[0] * x0 + b[3] * x1 + b[6] * x2; s1 += b[1] * x0 + b[4] * x1 + b[7] * x2; s2 += b[2] * x0 + b[5] * x1 + b[8] * x2;
+                s0 += b[0] * x0 + b[1] * x1 + b[2] * x2; s1 += b[3] * x0 + b[4] * x1 + b[5] * x2; s2 += b[6] * x0 + b[7] * x1 + b[8] * x2;
             }
         s0 = group_sum<T, 32>(s0); s1 = group_sum<T, 32>(s1); s2 = group_sum<T, 32>(s2);
         if (a < n_agg && sub == 0) { rc[3 * a] = s0; rc[3 * a + 1] = s1; rc[3 * a + 2] = s2; }

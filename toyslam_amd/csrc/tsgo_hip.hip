@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -77,9 +78,9 @@ template <typename T> struct DevLevel {      // device copy of one AmgLevel (hos
     int n = 0, n_agg = 0, nnzA = 0, nnzP = 0, nnzT = 0, nnzNext = 0;
     int *A_ptr = nullptr, *A_col = nullptr, *A_row = nullptr, *diag = nullptr;
     int *P_ptr = nullptr, *P_col = nullptr, *P_row = nullptr, *p_self = nullptr, *ps_ptr = nullptr, *ps_x = nullptr, *ps_y = nullptr;
-    int *R_ptr = nullptr, *R_col = nullptr, *r_to_p = nullptr;
+    int *R_ptr = nullptr, *R_col = nullptr, *r_to_p = nullptr, *p_to_r = nullptr;
     int *ts_ptr = nullptr, *ts_x = nullptr, *ts_y = nullptr, *as_ptr = nullptr, *as_x = nullptr, *as_y = nullptr;
-    T *rel = nullptr, *A = nullptr, *Dinv = nullptr, *P = nullptr, *Tv = nullptr;
+    T *rel = nullptr, *A = nullptr, *Dinv = nullptr, *P = nullptr, *Tv = nullptr, *Rv = nullptr;
     T *r = nullptr, *z = nullptr, *res = nullptr, *z2 = nullptr;
 };
 
@@ -111,8 +112,11 @@ template <typename T> struct Engine : IEngine {
     int *last_ptr = nullptr, *last_col = nullptr; int nb_last = 0, nnz_last = 0;
     T *A_last = nullptr, *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr;
     double ms_amg_symbolic = 0;
+    int coarse_sweeps = kCoarseSweeps;
 
-    explicit Engine(const tsgo_config& c) : cfg(c) {}
+    explicit Engine(const tsgo_config& c) : cfg(c) {
+        if (const char* e = getenv("TSGO_COARSE_SWEEPS")) coarse_sweeps = std::max(1, std::min(4, atoi(e)));
+    }
 
     ~Engine() override { release(); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 
@@ -183,12 +187,14 @@ template <typename T> struct Engine : IEngine {
             UP(D.P_ptr, L.P.ptr); UP(D.P_col, L.P.col); UP(D.P_row, rows_of(L.P)); UP(D.p_self, L.p_self);
             UP(D.ps_ptr, L.p_src.ptr); UP(D.ps_x, L.p_src.x); UP(D.ps_y, L.p_src.y);
             UP(D.R_ptr, L.R.ptr); UP(D.R_col, L.R.col); UP(D.r_to_p, L.r_to_p);
+            { std::vector<int> inv(L.r_to_p.size()); for (size_t k = 0; k < inv.size(); ++k) inv[L.r_to_p[k]] = (int)k; UP(D.p_to_r, inv); }
             UP(D.ts_ptr, L.t_src.ptr); UP(D.ts_x, L.t_src.x); UP(D.ts_y, L.t_src.y);
             UP(D.as_ptr, L.a_src.ptr); UP(D.as_x, L.a_src.x); UP(D.as_y, L.a_src.y);
             if (int rc = upload_T(&D.rel, L.rel.data(), L.rel.size())) return rc;
             if (int rc = dalloc(&D.A, (size_t)D.nnzA * 9)) return rc;
             if (int rc = dalloc(&D.Dinv, (size_t)D.n * 9)) return rc;
             if (int rc = dalloc(&D.P, (size_t)D.nnzP * 9)) return rc;
+            if (int rc = dalloc(&D.Rv, (size_t)D.nnzP * 9)) return rc;
             if (int rc = dalloc(&D.Tv, (size_t)D.nnzT * 9)) return rc;
             if (l > 0) {
                 if (int rc = dalloc(&D.r, (size_t)D.n * 3)) return rc;
@@ -308,7 +314,7 @@ template <typename T> struct Engine : IEngine {
             T* Anext = l + 1 < lv.size() ? lv[l + 1].A : A_last;
             hipLaunchKernelGGL((k_block_inv<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.diag, (const T*)L.A, L.Dinv);
             hipLaunchKernelGGL((k_prolongator<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, L.P_row, L.p_self, L.ps_ptr, L.ps_x, L.ps_y,
-                               (const T*)L.A, (const T*)L.Dinv, (const T*)L.rel, (T)kProlongOmega, L.P);
+                               (const T*)L.A, (const T*)L.Dinv, (const T*)L.rel, (T)kProlongOmega, L.P, L.p_to_r, L.Rv);
             hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for((L.nnzT + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const T*)L.A, (const T*)L.P, L.Tv);
             hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.nnzNext + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const T*)L.P, (const T*)L.Tv, Anext);
         }
@@ -344,32 +350,48 @@ template <typename T> struct Engine : IEngine {
         {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P, (const T*)r, (const T*)sbuf, lv[1].r, (const T*)lv[1].Dinv, lv[1].z, s);
+            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, (const T*)r, (const T*)sbuf, lv[1].r, (const T*)lv[1].Dinv, lv[1].z, s);
         }
+        // coarse levels: V(nu,nu) with nu = coarse_sweeps block-Jacobi sweeps (the first pre-sweep comes fused
+        // with the restriction above).  The current iterate alternates between L.z and L.z2; it ends in L.z2.
+        const int nu = coarse_sweeps;
         for (size_t l = 1; l < nl; ++l) {
             DevLevel<T>& L = lv[l];
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
-            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)L.z, (const T*)L.Dinv, L.res, s);
+            T* cur = L.z; T* oth = L.z2;
+            for (int sw = 1; sw < nu; ++sw) {
+                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, oth, s);
+                std::swap(cur, oth);
+            }
+            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, L.res, s);
             if (l + 1 < nl) {
                 const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const T*)lv[l + 1].Dinv, lv[l + 1].z, s);
+                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const T*)lv[l + 1].Dinv, lv[l + 1].z, s);
             }
         }
+        // iterate of level l after the down pass: L.z when nu is odd, L.z2 when even
+        auto down_iter = [&](DevLevel<T>& L) { return (nu % 2) ? L.z : L.z2; };
+        auto down_other = [&](DevLevel<T>& L) { return (nu % 2) ? L.z2 : L.z; };
         if (nl > 1) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
             DevLevel<T>& L = lv[nl - 1];
-            hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kDenseThreads), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, L.P_ptr, L.P_col, (const T*)L.P,
-                               (const T*)L.res, (const T*)inv_last, L.z, s);
+            hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kDenseThreads), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, L.P_ptr, L.P_col, (const T*)L.P,
+                               (const T*)L.res, (const T*)inv_last, down_iter(L), s);
         } else {        // only level 0 above the dense level: residual r - S z is restricted from (r, sbuf)
             DevLevel<T>& L = lv[0];
-            hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, L.r_to_p, (const T*)L.P,
+            hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv,
                                (const T*)r, (const T*)sbuf, r_last, (const T*)nullptr, (T*)nullptr, s);
             hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
         }
         for (size_t l = nl - 1; l >= 1; --l) {
             DevLevel<T>& L = lv[l];
-            if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, L.z, 3, s);
+            T* cur = down_iter(L); T* oth = down_other(L);
+            if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, cur, 3, s);
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
-            LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)L.z, (const T*)L.Dinv, L.z2, s);
+            for (int sw = 0; sw < nu; ++sw) {
+                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, oth, s);
+                std::swap(cur, oth);
+            }
+            // nu post-sweeps after nu-1 pre-swaps: the result sits in L.z2 for every nu (odd+odd / even+even swaps)
         }
         launch_prolong(lv[0], nl > 1 ? (const T*)lv[1].z2 : (const T*)z_last, zc, kPoseRec, s);
         launch_matvec(slot);

@@ -129,70 +129,10 @@ struct Twin {
         }
     }
 
-    // EXPERIMENT: exact solves on the level-0 aggregates as the smoother
-    std::vector<std::vector<double>> seg_inv; std::vector<std::vector<int>> seg_nodes;
-    void build_seg_smoother() {
-        const tsgo::AmgLevel& L = amg.levels[0];
-        seg_nodes.assign(L.n_agg, {}); seg_inv.assign(L.n_agg, {});
-        for (int i = 0; i < P; ++i) seg_nodes[L.agg[i]].push_back(i);
-        std::vector<int> local(P, -1);
-        for (int a = 0; a < L.n_agg; ++a) {
-            const auto& nd = seg_nodes[a]; const int m = (int)nd.size() * 3;
-            for (size_t q = 0; q < nd.size(); ++q) local[nd[q]] = (int)q;
-            std::vector<double> M((size_t)m * m, 0.0), I((size_t)m * m, 0.0);
-            for (size_t q = 0; q < nd.size(); ++q) {
-                const int i = nd[q];
-                for (int b = L.A.ptr[i]; b < L.A.ptr[i + 1]; ++b) {
-                    const int k = L.A.col[b];
-                    if (L.agg[k] != a) continue;
-                    for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) M[(size_t)(3 * q + x) * m + 3 * local[k] + y] = hier.A[0][(size_t)b * 9 + 3 * x + y];
-                }
-            }
-            for (int d = 0; d < m; ++d) I[(size_t)d * m + d] = 1;
-            for (int c = 0; c < m; ++c) {
-                const double d = M[(size_t)c * m + c];
-                for (int j = 0; j < m; ++j) { M[(size_t)c * m + j] /= d; I[(size_t)c * m + j] /= d; }
-                for (int rr = 0; rr < m; ++rr) if (rr != c) { const double f = M[(size_t)rr * m + c]; if (f != 0) for (int j = 0; j < m; ++j) { M[(size_t)rr * m + j] -= f * M[(size_t)c * m + j]; I[(size_t)rr * m + j] -= f * I[(size_t)c * m + j]; } }
-            }
-            seg_inv[a] = I;
-        }
-    }
-    void seg_apply(const std::vector<double>& in, std::vector<double>& out, bool add) {
-        for (size_t a = 0; a < seg_nodes.size(); ++a) {
-            const auto& nd = seg_nodes[a]; const int m = (int)nd.size() * 3;
-            for (int x = 0; x < m; ++x) {
-                double sacc = 0;
-                for (int y = 0; y < m; ++y) sacc += seg_inv[a][(size_t)x * m + y] * in[3 * (size_t)nd[y / 3] + y % 3];
-                double& o = out[3 * (size_t)nd[x / 3] + x % 3];
-                o = add ? o + sacc : sacc;
-            }
-        }
-    }
-
     // z = M^-1 r by one V(1,1) cycle (level 0 uses the implicit Schur product)
     void amg_apply() {
-        static const bool seg = getenv("TSGO_TWIN_SEGSMOOTH") != nullptr;
-        if (seg && !amg.levels.empty()) {
-            seg_apply(r, z, false);
-            schur_lm(z); schur_pose(z, s0);
-            for (size_t k = 0; k < s0.size(); ++k) res0[k] = r[k] - s0[k];
-            hier.restrict_to(0, res0, hier.r[1]);
-            hier.cycle(1);
-            hier.prolong_add(0, hier.z[1], z);
-            schur_lm(z); schur_pose(z, s0);
-            for (size_t k = 0; k < s0.size(); ++k) res0[k] = r[k] - s0[k];
-            seg_apply(res0, z, true);
-            return;
-        }
         for (int i = 0; i < P; ++i) tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
         if (amg.levels.empty()) return;
-        static const bool additive = getenv("TSGO_TWIN_ADDITIVE") != nullptr;
-        if (additive) {
-            hier.restrict_to(0, r, hier.r[1]);
-            hier.cycle(1);
-            hier.prolong_add(0, hier.z[1], z);
-            return;
-        }
         schur_lm(z); schur_pose(z, s0);
         for (size_t k = 0; k < s0.size(); ++k) res0[k] = r[k] - s0[k];
         hier.restrict_to(0, res0, hier.r[1]);
@@ -386,7 +326,7 @@ struct Twin {
         const double g0 = finalize();
         if (use_amg) {
             static const int lag = getenv("TSGO_TWIN_LAG") ? atoi(getenv("TSGO_TWIN_LAG")) : 1;
-            if (!amg.levels.empty() && (n_lin % lag) == 0) { build_schur_blocks(); hier.setup_from_level0(); if (getenv("TSGO_TWIN_SEGSMOOTH")) build_seg_smoother(); }
+            if (!amg.levels.empty() && (n_lin % lag) == 0) { build_schur_blocks(); hier.setup_from_level0(); }
             ++n_lin;
             amg_apply();
             double g = 0;

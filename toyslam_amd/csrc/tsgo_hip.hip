@@ -72,7 +72,7 @@ struct IEngine {
 };
 
 constexpr int kChunk = 16;   // PCG iterations per captured hipGraph (even: the state ring has 2 slots)
-constexpr int kChunkAmg = 4; // with the multigrid V-cycle an iteration is ~30 launches and a solve ~50 iterations
+constexpr int kChunkAmg = 2; // with the multigrid V-cycle an iteration is ~30 launches and a solve ~50 iterations
 
 template <typename T> struct DevLevel {      // device copy of one AmgLevel (host/amg.h) + its numeric arrays
     int n = 0, n_agg = 0, nnzA = 0, nnzP = 0, nnzT = 0, nnzNext = 0;

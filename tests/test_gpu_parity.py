@@ -196,3 +196,19 @@ def test_c3_full_size_properties():
     assert e1 < e0
     # (4) the fixed vertex stays put (gauge 1e6)
     assert np.abs(v[0] - g.v_pos[0]).max() < 1e-3
+
+
+def test_c3_one_full_size_step_matches_the_cpu_twin():
+    """BASELINE config 3 at FULL size: one Gauss-Newton step (linearise + solve, tol 1e-12) on the GPU against
+    the CPU twin of the sparse path (itself pinned to the dense restatement at small sizes)."""
+    g = synth.make_config("c3_100k")
+    ref = oracle.sparse_step(util.to_oracle(g), 1e-12, precond="amg")
+    o = HipOptimizer(pcg_rel_tol=1e-12)
+    try:
+        o.set_graph(g)
+        r = o.solve_step()
+    finally:
+        o.close()
+    assert abs(r["chi2"] - ref["chi2"]) <= 1e-11 * ref["chi2"]
+    assert np.abs(r["delta"] - ref["delta"]).max() <= 1e-7 * np.abs(ref["delta"]).max()   # north_star: 1e-6
+    assert r["cg_iters"] < 150

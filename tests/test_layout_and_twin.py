@@ -155,3 +155,26 @@ def test_twin_multigrid_full_run_c1_matches_dense():
     np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-10)
     assert util.max_vertex_diff(r["v_pos"], ref["v_pos"], g.v_type) < 1e-9
     assert r["cg_iters"].max() < 30
+
+
+def test_hub_landmark_keeps_the_multigrid_lists_bounded_and_the_answer_exact():
+    """One landmark observed from every pose (d = 400 -> 160 000 pose pairs) must not blow up the
+    preconditioner's gather lists, and the solve stays exact."""
+    g = synth.make(400, 6, seed=9)
+    P = g.n_poses
+    hub = g.v_id[g.v_type == 1][0]
+    extra = P
+    g2 = util.to_arrays(g)
+    import numpy as np
+    e_type = np.concatenate([g.e_type, np.ones(extra, np.uint32)])
+    e_ids = np.concatenate([g.e_ids, np.stack([np.arange(P, dtype=np.uint32), np.full(P, hub, np.uint32)], 1)])
+    meas = np.zeros((extra, 9)); meas[:, 0] = 5.0; meas[:, 1] = np.linspace(-1, 1, extra)
+    inf = np.tile([1.0, 1.0, 0.0], (extra, 1))
+    from toyslam_amd.graph import GraphArrays
+    g2 = GraphArrays(g.v_id, g.v_type, g.v_pos, e_type, e_ids, np.concatenate([g.e_meas, meas]), np.concatenate([g.e_inf, inf]), g.fixed)
+    lib = _lib.host_lib(); info = _lib.tsgo_amg_info(); cg = g2.c_struct()
+    _lib.check(lib, lib.tsgo_amg_probe(C.byref(cg), C.byref(info)), "tsgo_amg_probe")
+    assert info.schur_contribs < 40 * len(e_type)
+    d_ref, err, _, _ = util.dense_solution(g2)
+    r = oracle.sparse_step(util.to_oracle(g2), 1e-12, precond="amg")
+    assert np.abs(r["delta"] - d_ref).max() <= 1e-8 * np.abs(d_ref).max()

@@ -229,6 +229,10 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
                 row.clear();
                 for_slots(pr.by_pose, i, [&](size_t k) {
                     const int l = (int)pr.by_pose.idx[k];
+                    // a landmark seen from d poses couples d^2 pose pairs; beyond kMaxPairDegree its couplings are
+                    // left out of the PRECONDITIONER's explicit matrix (its diagonal part stays; the Schur
+                    // product itself is exact either way), which bounds the list memory on hub landmarks
+                    if (obs_ptr[l + 1] - obs_ptr[l] > kMaxPairDegree) return;
                     for (int q = obs_ptr[l]; q < obs_ptr[l + 1]; ++q)
                         if (obs_pose[q] != i) row.push_back({obs_pose[q], (uint32_t)k, obs_slot[q], 0});
                 });

@@ -22,6 +22,7 @@ namespace tsgo {
 
 constexpr int kAggSize = 8;          // nodes per aggregate
 constexpr int kCoarsestMax = 28;     // stop coarsening at <= this many block rows (dense inverse in LDS, <= 84 x 84)
+constexpr int kMaxPairDegree = 64;    // landmarks observed from more poses than this do not add off-diagonal level-0 blocks
 constexpr double kProlongOmega = 0.7;
 constexpr int kCoarseSweeps = 2;      // block-Jacobi sweeps per side on the coarse levels: V(1,1) on level 0, V(2,2) below
                                       // (100k poses: 66 -> 53 PCG iterations for +30 us per iteration)

@@ -62,8 +62,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
     for (int q = sptr[b]; q < sptr[b + 1]; ++q) {
         const size_t e1 = slot_i[q], e2 = slot_k[q];
         const uint32_t l = tb.idx[e1];
-        const T a0i = tb.dyn[e1], a1i = tb.dyn[S + e1], vi0 = tb.dyn[3 * S + e1], vi1 = -tb.dyn[2 * S + e1];
-        const T a0k = tb.dyn[e2], a1k = tb.dyn[S + e2], vk0 = tb.dyn[3 * S + e2], vk1 = -tb.dyn[2 * S + e2];
+        const auto ai = ld2<T>(tb.dyn + 2 * e1), pi = ld2<T>(tb.dyn + 2 * (S + e1));
+        const auto ak = ld2<T>(tb.dyn + 2 * e2), pk = ld2<T>(tb.dyn + 2 * (S + e2));
+        const T a0i = ai.x, a1i = ai.y, vi0 = pi.y, vi1 = -pi.x;
+        const T a0k = ak.x, a1k = ak.y, vk0 = pk.y, vk1 = -pk.x;
         const T* lr = lmrec + (size_t)l * kLmRec;
         const T nxx = lr[2], nxy = lr[3], nyy = lr[4];
         const T m00 = nxx * ck + nxy * sk, m01 = nxy * ck - nxx * sk, m10 = nxy * ck + nyy * sk, m11 = nyy * ck - nxy * sk;

@@ -219,12 +219,21 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
 
-    int upload_table(Table<T>& t, const SellTable& h, int dyn_planes) {
-        t.slots = h.slots(); t.n_slices = h.n_slices; t.n_vertices = h.n_vertices; t.xcd = cfg.xcd_map;
+    int upload_table(Table<T>& t, const SellTable& h, int dyn_planes, bool pairs) {
+        t.slots = h.slots(); t.n_slices = h.n_slices; t.n_vertices = h.n_vertices; t.xcd = cfg.xcd_map ? 1 : 0;
         if (int rc = upload_u32(&t.row_off, h.row_off)) return rc;
         if (int rc = upload_u32(&t.idx, h.idx)) return rc;
         T* stp = nullptr;
-        if (int rc = upload_T(&stp, h.planes.data(), h.planes.size())) return rc;
+        std::vector<double> inter;
+        const double* src = h.planes.data();
+        if (pairs) {      // plane-major (zx | zy | w0 | w1) -> pair-plane-major ((zx,zy) | (w0,w1))
+            const size_t S = h.slots();
+            inter.resize(h.planes.size());
+            for (int q = 0; q < h.n_planes / 2; ++q)
+                for (size_t k = 0; k < S; ++k) { inter[((size_t)q * S + k) * 2] = h.plane(2 * q)[k]; inter[((size_t)q * S + k) * 2 + 1] = h.plane(2 * q + 1)[k]; }
+            src = inter.data();
+        }
+        if (int rc = upload_T(&stp, src, h.planes.size())) return rc;
         t.st = stp;
         if (int rc = dalloc(&t.dyn, (size_t)dyn_planes * h.slots())) return rc;
         HIP_OK(hipMemset(t.dyn, 0, std::max<size_t>((size_t)dyn_planes * h.slots(), 1) * sizeof(T)));
@@ -254,9 +263,9 @@ template <typename T> struct Engine : IEngine {
         if (int rc = upload_T(&lmrec, lm_h.data(), lm_h.size())) return rc;
         if (int rc = upload_T(&gauge_p, pr.gauge_p.data(), pr.gauge_p.size())) return rc;
         if (int rc = upload_T(&gauge_l, pr.gauge_l.data(), pr.gauge_l.size())) return rc;
-        if (int rc = upload_table(tp, pr.by_pose, 4)) return rc;
-        if (int rc = upload_table(tl, pr.by_lm, 4)) return rc;
-        if (int rc = upload_table(to, pr.odom, 3)) return rc;
+        if (int rc = upload_table(tp, pr.by_pose, 4, true)) return rc;
+        if (int rc = upload_table(tl, pr.by_lm, 4, true)) return rc;
+        if (int rc = upload_table(to, pr.odom, 3, false)) return rc;
         // table-kernel grids are multiples of 8 (one eighth of the slices per XCD, see xcd_block())
         nbP = 8 * (((tp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);
         nbL = 8 * (((tl.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);

@@ -42,8 +42,17 @@ template <typename T> __device__ __forceinline__ typename Pair<T>::type ld2(cons
     return *reinterpret_cast<const typename Pair<T>::type*>(p);
 }
 
+template <typename T> __device__ __forceinline__ void st2(T* p, T a, T b) {
+    typename Pair<T>::type v; v.x = a; v.y = b;
+    *reinterpret_cast<typename Pair<T>::type*>(p) = v;
+}
+
 template <typename T> struct CgState { T gamma_old, alpha_old, gamma0, pad; int iters, done, fail, pad2; };
 
+// LM tables keep their per-slot values as 16-byte PAIRS, pair-plane-major: st = [(zx,zy) | (w0,w1)],
+// dyn = [(a0,a1) | (ppx,ppy)], element k of pair-plane q at (q*slots + k)*2: one dwordx4 per lane and
+// plane instead of two dwordx2 (8-byte lanes stream at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).
+// The ODOM table keeps single-value planes.
 template <typename T> struct Table {       // one SELL table on the device
     const uint32_t* row_off; const uint32_t* idx; const T* st; T* dyn; size_t slots; int n_slices; int n_vertices; int xcd;
 };
@@ -108,12 +117,13 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restr
     for (uint32_t row = r0; row < r1; ++row) {
         const size_t k = (size_t)row * 64 + lane;
         const uint32_t i = tb.idx[k];
-        const T zx = tb.st[k], zy = tb.st[S + k], w0 = tb.st[2 * S + k], w1 = tb.st[3 * S + k];
+        const auto zz = ld2<T>(tb.st + 2 * k), ww = ld2<T>(tb.st + 2 * (S + k));
+        const T zx = zz.x, zy = zz.y, w0 = ww.x, w1 = ww.y;
         const T* q = ps + (size_t)i * 4;
         const auto q01 = ld2<T>(q), q23 = ld2<T>(q + 2);
         const T x = q01.x, y = q01.y, c = q23.x, s = q23.y;
         const LmLin<T> o = lm_linearize<T>(x, y, c, s, lx, ly, zx, zy, w0, w1);
-        tb.dyn[k] = o.a0; tb.dyn[S + k] = o.a1; tb.dyn[2 * S + k] = o.ppx; tb.dyn[3 * S + k] = o.ppy;
+        st2<T>(tb.dyn + 2 * k, o.a0, o.a1); st2<T>(tb.dyn + 2 * (S + k), o.ppx, o.ppy);
         dxx += o.a0 * c * c + o.a1 * s * s; dxy += (o.a0 - o.a1) * c * s; dyy += o.a0 * s * s + o.a1 * c * c;
         const T f0 = o.a0 * o.e0, f1 = o.a1 * o.e1;
         g0 -= c * f0 - s * f1; g1 -= s * f0 + c * f1;
@@ -157,12 +167,13 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
             for (uint32_t row = r0; row < r1; ++row) {
                 const size_t k = (size_t)row * 64 + lane;
                 const uint32_t l = tb.idx[k];
-                const T zx = tb.st[k], zy = tb.st[S + k], w0 = tb.st[2 * S + k], w1 = tb.st[3 * S + k];
+                const auto zz = ld2<T>(tb.st + 2 * k), ww = ld2<T>(tb.st + 2 * (S + k));
+                const T zx = zz.x, zy = zz.y, w0 = ww.x, w1 = ww.y;
                 const T* lr = lmrec + (size_t)l * kLmRec;
                 const auto l01 = ld2<T>(lr), l23 = ld2<T>(lr + 2), l45 = ld2<T>(lr + 4);
                 const T lx = l01.x, ly = l01.y, nxx = l23.x, nxy = l23.y, nyy = l45.x, ux = l45.y, uy = lr[6];
                 const LmLin<T> o = lm_linearize<T>(x0, y0, c, s, lx, ly, zx, zy, w0, w1);
-                tb.dyn[k] = o.a0; tb.dyn[S + k] = o.a1; tb.dyn[2 * S + k] = o.ppx; tb.dyn[3 * S + k] = o.ppy;
+                st2<T>(tb.dyn + 2 * k, o.a0, o.a1); st2<T>(tb.dyn + 2 * (S + k), o.ppx, o.ppy);
                 chi += o.rho;
                 const T v0 = o.ppy, v1 = -o.ppx;
                 sA0 += o.a0; sA1 += o.a1; sAv0 += o.a0 * v0; sAv1 += o.a1 * v1; sVV += o.a0 * v0 * v0 + o.a1 * v1 * v1;
@@ -285,22 +296,44 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
         T acc0 = 0, acc1 = 0;
         const size_t S = tb.slots;
         const uint32_t r0 = tb.row_off[slice], r1 = tb.row_off[slice + 1];
-#pragma unroll 2
-        for (uint32_t row = r0; row < r1; ++row) {
-            const size_t k = (size_t)row * 64 + lane;
-            const uint32_t i = tb.idx[k];
-            const T a0 = tb.dyn[k], a1 = tb.dyn[S + k], ppx = tb.dyn[2 * S + k], ppy = tb.dyn[3 * S + k];
-            const T* zr = zc + (size_t)i * kPoseRec;
-            const auto z01 = ld2<T>(zr), z23 = ld2<T>(zr + 2);
-            const T v0 = z01.x, v1 = z01.y, v2 = z23.x, c = z23.y, s = zr[4];
-            const T vt0 = c * v0 + s * v1, vt1 = c * v1 - s * v0;
-            const T m0 = a0 * (ppy * v2 - vt0), m1 = a1 * (-vt1 - ppx * v2);
-            acc0 += c * m0 - s * m1; acc1 += s * m0 + c * m1;
+        // the inverse block this vertex needs at the very end is requested first: its latency hides behind the rows
+        const int lq = (l < tb.n_vertices) ? l : tb.n_vertices - 1;
+        const auto n01 = ld2<T>(lmrec + (size_t)lq * kLmRec + 2);
+        const T n2 = lmrec[(size_t)lq * kLmRec + 4];
+        // UB rows are walked at a time with every load of the batch issued before any use: a wave's time is
+        // the depth of its dependent-load chain (row -> index -> gathered pose record), so memory-level
+        // parallelism is what buys time.  Rows past the end are clamped (in bounds) and masked out of the sums.
+        constexpr int UB = (G >= 4) ? 2 : 4;
+        for (uint32_t base = r0; base < r1; base += UB) {
+            uint32_t i[UB]; T a0[UB], a1[UB], ppx[UB], ppy[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const uint32_t row = min(base + u, r1 - 1);
+                const size_t k = (size_t)row * 64 + lane;
+                i[u] = tb.idx[k];
+                const auto aa = ld2<T>(tb.dyn + 2 * k), pp = ld2<T>(tb.dyn + 2 * (S + k));
+                a0[u] = aa.x; a1[u] = aa.y; ppx[u] = pp.x; ppy[u] = pp.y;
+            }
+            T v0[UB], v1[UB], v2[UB], c[UB], s[UB];
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                const T* zr = zc + (size_t)i[u] * kPoseRec;
+                const auto z01 = ld2<T>(zr), z23 = ld2<T>(zr + 2);
+                v0[u] = z01.x; v1[u] = z01.y; v2[u] = z23.x; c[u] = z23.y; s[u] = zr[4];
+            }
+#pragma unroll
+            for (int u = 0; u < UB; ++u) {
+                if (base + u < r1) {
+                    const T vt0 = c[u] * v0[u] + s[u] * v1[u], vt1 = c[u] * v1[u] - s[u] * v0[u];
+                    const T m0 = a0[u] * (ppy[u] * v2[u] - vt0), m1 = a1[u] * (-vt1 - ppx[u] * v2[u]);
+                    acc0 += c[u] * m0 - s[u] * m1; acc1 += s[u] * m0 + c[u] * m1;
+                }
+            }
         }
         acc0 = group_sum<T, G>(acc0); acc1 = group_sum<T, G>(acc1);
         if (l < tb.n_vertices && (lane % G) == 0) {
             T* lr = lmrec + (size_t)l * kLmRec;
-            const T ixx = lr[2], ixy = lr[3], iyy = lr[4];
+            const T ixx = n01.x, ixy = n01.y, iyy = n2;
             const T t0 = ixx * acc0 + ixy * acc1, t1 = ixy * acc0 + iyy * acc1;
             if (MODE == 0) { t[(size_t)l * 2] = t0; t[(size_t)l * 2 + 1] = t1; }
             else {
@@ -347,7 +380,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
             for (uint32_t row = r0; row < r1; ++row) {
                 const size_t k = (size_t)row * 64 + lane;
                 const uint32_t l = tb.idx[k];
-                const T a0 = tb.dyn[k], a1 = tb.dyn[S + k], ppx = tb.dyn[2 * S + k], ppy = tb.dyn[3 * S + k];
+                const auto aa = ld2<T>(tb.dyn + 2 * k), pp = ld2<T>(tb.dyn + 2 * (S + k));
+                const T a0 = aa.x, a1 = aa.y, ppx = pp.x, ppy = pp.y;
                 const auto txy = ld2<T>(t + (size_t)l * 2);
                 const T tx = txy.x, ty = txy.y;
                 const T t0 = a0 * (c * tx + s * ty), t1 = a1 * (c * ty - s * tx);

@@ -77,6 +77,8 @@ typedef struct tsgo_stats {
     double ms_setup;                     /* host layout build + upload in tsgo_set_graph */
     int64_t n_pose, n_lm, n_odom_edges, n_lm_edges;
     int64_t pcg_iters_total;
+    int32_t pcg_fallbacks;               /* solves repeated with block-Jacobi after a multigrid breakdown */
+    int32_t reserved;
 } tsgo_stats;
 
 /* Fills cfg with defaults. */

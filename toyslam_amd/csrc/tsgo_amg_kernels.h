@@ -339,6 +339,23 @@ __global__ __launch_bounds__(kBlock) void k_smooth0(int P, const T* __restrict__
     if (MODE == 0) { zr[0] = z0; zr[1] = z1; zr[2] = z2; } else { zr[0] += z0; zr[1] += z1; zr[2] += z2; }
 }
 
+// r^T D^-1 r partials (D = the 3x3 Schur diagonal): an SPD norm of the residual that does not involve the
+// multigrid operator, used once per solve to certify convergence independently of the preconditioner.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_resid_norm(int P, const T* __restrict__ minv, const T* __restrict__ r, T* __restrict__ part) {
+    __shared__ T red[kWavesPerBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    T g = 0;
+    if (i < P) {
+        T z0, z1, z2;
+        const T r0 = r[(size_t)i * 3], r1 = r[(size_t)i * 3 + 1], r2 = r[(size_t)i * 3 + 2];
+        sym3_mul<T>(minv + (size_t)i * 6, r0, r1, r2, z0, z1, z2);
+        g = r0 * z0 + r1 * z1 + r2 * z2;
+    }
+    const T total = block_sum<T>(g, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+
 // PCG vector step when the preconditioner is applied by separate kernels (the V-cycle):
 //   gamma = (r, z), delta = (S z, z) arrive as partials; p = z + beta p, q = S z + beta q,
 //   x += alpha p, r -= alpha q.  z for the next iteration comes from the next V-cycle.

@@ -71,6 +71,7 @@ struct IEngine {
     ncclComm_t comm = nullptr;
 };
 
+constexpr double kCertifySlack = 1e4;   // certificate: sqrt(r^T D^-1 r / b^T D^-1 b) <= slack * tol (norms differ by up to ~sqrt(cond))
 constexpr int kChunk = 16;   // PCG iterations per captured hipGraph (even: the state ring has 2 slots)
 constexpr int kChunkAmg = 2; // with the multigrid V-cycle an iteration is ~30 launches and a solve ~50 iterations
 
@@ -286,7 +287,7 @@ template <typename T> struct Engine : IEngine {
         for (int k = 0; k < 2; ++k) { if (int rc = dalloc(&gpart[k], nbC)) return rc; if (int rc = dalloc(&st[k], 1)) return rc; }
         if (int rc = dalloc(&npart, (size_t)nbC + std::max(nbL, 1))) return rc;
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
-        HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, nbC) + nbL + 8)));
+        HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
         HIP_OK(hipDeviceSynchronize());
         amg_on = cfg.preconditioner == 1 && pr.world == 1 && pr.P > kCoarsestMax;
         if (amg_on) { if (int rc = upload_amg()) return rc; }
@@ -457,6 +458,20 @@ template <typename T> struct Engine : IEngine {
     int n_fallbacks = 0;
     int do_solve(int* iters, int* fail) {
         if (int rc = do_solve_once(iters, fail)) return rc;
+        if (*fail == 0 && amg_on) {
+            // certify the multigrid-preconditioned solve in a norm the multigrid operator has no part in:
+            // r^T D^-1 r against b^T D^-1 b (partials left by k_pose_finalize in gpart[0]).  An indefinite
+            // preconditioner can make r^T M^-1 r small while r is not.
+            hipLaunchKernelGGL((k_resid_norm<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, npart);
+            HIP_OK(hipMemcpyAsync(h_scratch, npart, sizeof(T) * nbC, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipMemcpyAsync(h_scratch + nbC, gpart[0], sizeof(T) * nbC, hipMemcpyDeviceToHost, stream));
+            HIP_OK(hipStreamSynchronize(stream));
+            double num = 0, den = 0;
+            for (int k = 0; k < nbC; ++k) { num += (double)h_scratch[k]; den += (double)h_scratch[nbC + k]; }
+            const double lim = kCertifySlack * cfg.pcg_rel_tol;
+            if (getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] certificate: sqrt(rDr/bDb) = %.3e (tol %.1e, limit %.1e), %d iterations\n", std::sqrt(num / den), cfg.pcg_rel_tol, lim, *iters);
+            if (!(num <= lim * lim * den)) *fail = 1;
+        }
         if (*fail == 1 && amg_on) {
             ++n_fallbacks;
             const bool keep = amg_on; hipGraphExec_t g = cg_graph;
@@ -527,6 +542,7 @@ template <typename T> struct Engine : IEngine {
         s.n_pose = pr.P; s.n_lm = pr.L_total; s.n_odom_edges = pr.n_odom_edges_total; s.n_lm_edges = pr.n_lm_edges_total;
         s.ms_setup = ms_setup;
         double prevErr = -1; int penalty = 0;
+        const int fallbacks0 = n_fallbacks;
         s.stop_reason = TSGO_STOP_CAP;
         const auto wall0 = std::chrono::steady_clock::now();
         for (int it = 0; it < iterations; ++it) {
@@ -557,6 +573,7 @@ template <typename T> struct Engine : IEngine {
             if (nrm < kDeltaTol) { s.stop_reason = TSGO_STOP_CONVERGED; break; }                        // :173-177
             prevErr = err;                                                                              // :179
         }
+        s.pcg_fallbacks = n_fallbacks - fallbacks0;
         s.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         if (out) *out = s;
         return 0;

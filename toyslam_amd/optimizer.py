@@ -55,7 +55,7 @@ class HipOptimizer:
                     cg_iters=np.array(st.pcg_iters[:n]), delta_norm=st.last_delta_norm, ms_total=st.ms_total,
                     ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup,
                     n_pose=st.n_pose, n_lm=st.n_lm, n_odom_edges=st.n_odom_edges, n_lm_edges=st.n_lm_edges,
-                    cg_total=st.pcg_iters_total)
+                    cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks)
 
     def vertices(self):
         out = np.zeros((self.n_vertices, 3))

@@ -72,7 +72,9 @@ struct Hierarchy {
                     double* o = &P[l][(size_t)pb * 9];
                     static const double omega = getenv("TSGO_TWIN_OMEGA") ? atof(getenv("TSGO_TWIN_OMEGA")) : tsgo::kProlongOmega;
                     for (int m = 0; m < 9; ++m) o[m] = -omega * da[m];
-                    if (L.p_self[pb]) { o[0] += 1; o[4] += 1; o[8] += 1; o[2] += -L.rel[2 * (size_t)i + 1]; o[5] += L.rel[2 * (size_t)i]; }
+                    const double* dd = &Dinv[l][(size_t)i * 9];
+                    const bool dead = dd[0] == 0 && dd[4] == 0 && dd[8] == 0;       // vertex without edges: keep it out of the coarse space
+                    if (L.p_self[pb] && !dead) { o[0] += 1; o[4] += 1; o[8] += 1; o[2] += -L.rel[2 * (size_t)i + 1]; o[5] += L.rel[2 * (size_t)i]; }
                 }
             // T = A P
             for (int tb = 0; tb < L.T.nnz(); ++tb) {

@@ -1,0 +1,26 @@
+"""Edge-case graphs: the sparse CPU twin (both preconditioners) against the dense `cpu eigen` restatement."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import edge_cases, util
+
+
+@pytest.mark.parametrize("name", sorted(edge_cases.CASES))
+@pytest.mark.parametrize("precond", ["jacobi", "amg"])
+def test_twin_matches_dense_on_edge_cases(name, precond):
+    g = edge_cases.CASES[name]()
+    ref = oracle.optimize(util.to_oracle(g), 8, mode="cpp", solver="qr")
+    r = oracle.sparse_optimize(util.to_oracle(g), 8, pcg_tol=1e-13, precond=precond)
+    assert r["iters"] == ref["iters"] and r["stop"] == ref["stop"]
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
+    assert util.max_vertex_diff(r["v_pos"], ref["v_pos"], g.v_type) < 1e-8
+
+
+def test_vertex_and_edge_order_do_not_matter():
+    g = edge_cases.base()
+    gs, pv = edge_cases.shuffled_vertices_and_edges()
+    a = oracle.sparse_optimize(util.to_oracle(g), 6, pcg_tol=1e-13, precond="amg")
+    b = oracle.sparse_optimize(util.to_oracle(gs), 6, pcg_tol=1e-13, precond="amg")
+    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-10)
+    assert util.max_vertex_diff(a["v_pos"][pv], b["v_pos"], gs.v_type) < 1e-9

@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from tests import util
+from tests import edge_cases, util
 from toyslam_amd import synth
 from toyslam_amd.optimizer import HipOptimizer
 
@@ -233,3 +233,25 @@ def test_multigrid_breakdown_falls_back_to_block_jacobi(monkeypatch):
     np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
     assert util.max_vertex_diff(v, vref, g.v_type) < 1e-7
     assert r["fallbacks"] >= 0            # > 0 whenever the hierarchy is indefinite; either way the result holds
+
+
+@pytest.mark.parametrize("name", sorted(edge_cases.CASES))
+def test_edge_case_graphs_match_cpu_eigen(opt, name):
+    """Fixed landmarks / repeated fixed ids, vertices no edge touches, sparse 32-bit ids, no ODOM edges at all,
+    self loops and repeated edges: 8 iterations against the dense restatement (QR solver, like the reference)."""
+    g = edge_cases.CASES[name]()
+    ref = oracle.optimize(util.to_oracle(g), 8, mode="cpp", solver="qr")
+    opt.set_graph(g)
+    r = opt.optimize(8)
+    assert r["iters"] == ref["iters"] and r["stop"] == ref["stop"]
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
+    assert util.max_vertex_diff(opt.vertices(), ref["v_pos"], g.v_type) < 1e-8
+
+
+def test_vertex_and_edge_order_do_not_matter_on_the_device(opt):
+    g = edge_cases.base()
+    gs, pv = edge_cases.shuffled_vertices_and_edges()
+    opt.set_graph(g); a = opt.optimize(6); va = opt.vertices()
+    opt.set_graph(gs); b = opt.optimize(6); vb = opt.vertices()
+    np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-10)
+    assert util.max_vertex_diff(va[pv], vb, gs.v_type) < 1e-9

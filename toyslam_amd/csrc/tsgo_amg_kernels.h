@@ -125,7 +125,10 @@ __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __r
     T o[9];
 #pragma unroll
     for (int m = 0; m < 9; ++m) o[m] = -omega * da[m];
-    if (p_self[pb]) { o[0] += T(1); o[4] += T(1); o[8] += T(1); o[2] -= rel[(size_t)i * 2 + 1]; o[5] += rel[(size_t)i * 2]; }
+    // a node whose diagonal block is singular (a vertex no edge touches: Dinv was set to 0) stays out of the
+    // coarse space, otherwise the cycle would inject a null-space component that nothing removes
+    const bool dead = d[0] == T(0) && d[4] == T(0) && d[8] == T(0);
+    if (p_self[pb] && !dead) { o[0] += T(1); o[4] += T(1); o[8] += T(1); o[2] -= rel[(size_t)i * 2 + 1]; o[5] += rel[(size_t)i * 2]; }
 #pragma unroll
     for (int m = 0; m < 9; ++m) P[(size_t)pb * 9 + m] = o[m];
     // the same block transposed, stored in the order the restriction walks it (rows of R = P^T):

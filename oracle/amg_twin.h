@@ -2,6 +2,7 @@
 // (toyslam_amd/csrc/tsgo_amg_kernels.h), operating on the product's symbolic hierarchy (host/amg.h).
 #pragma once
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -35,6 +36,7 @@ struct Hierarchy {
     std::vector<double> A_last, inv_last;               // coarsest: block values, dense inverse (n x n)
     int n_last = 0;
     std::vector<std::vector<double>> r, z, res, z2;     // per level work vectors (3 per node), level 0 unused for r
+    std::vector<double> omega;                          // smoother damping per level (power-iteration estimate)
 
     void alloc(const AmgSym& s) {
         sym = &s;
@@ -91,6 +93,24 @@ struct Hierarchy {
                 std::memcpy(&An[(size_t)ab * 9], acc, 72);
             }
         }
+        // smoother damping per level: 16 power steps on D^-1 A from a fixed start vector, exactly as the device
+        // does (tsgo_hip.hip, estimate_damping): omega = min(1, 1.6 / (1.05 rho))
+        omega.assign(nl, tsgo::kSmootherOmega);
+        for (size_t l = 0; l < nl; ++l) {
+            const AmgLevel& L = sym->levels[l];
+            std::vector<double> v((size_t)L.n * 3), w((size_t)L.n * 3), u((size_t)L.n * 3);
+            for (size_t k = 0; k < v.size(); ++k) v[k] = std::sin(0.37 * (double)k) + 0.1;
+            double nk = 0, nk1 = 0;
+            for (int it = 0; it < 16; ++it) {
+                spmv(L.A, A[l], v, w);
+                for (int i = 0; i < L.n; ++i) { const double* d = &Dinv[l][(size_t)i * 9]; const double* x = &w[(size_t)i * 3]; for (int c = 0; c < 3; ++c) u[(size_t)i * 3 + c] = d[3 * c] * x[0] + d[3 * c + 1] * x[1] + d[3 * c + 2] * x[2]; }
+                nk1 = 0; for (double x : v) nk1 += x * x;
+                nk = 0; for (double x : u) nk += x * x;
+                v.swap(u);
+            }
+            if (nk > 0 && nk1 > 0) omega[l] = std::min(1.0, 1.6 / (1.05 * std::sqrt(nk / nk1)));
+            if (getenv("TSGO_TWIN_RHO")) std::fprintf(stderr, "[twin] level %zu: n = %d, blocks/row = %.1f, rho ~ %.3f, omega = %.3f\n", l, L.n, (double)L.A.nnz() / L.n, std::sqrt(nk / nk1), omega[l]);
+        }
         // coarsest: dense inverse by Gauss-Jordan (SPD, no pivoting needed; partial pivoting kept for safety)
         const int n = n_last;
         std::vector<double> M((size_t)n * n, 0.0);
@@ -126,11 +146,11 @@ struct Hierarchy {
             y[(size_t)i * 3] = s0; y[(size_t)i * 3 + 1] = s1; y[(size_t)i * 3 + 2] = s2;
         }
     }
-    static void dinv_apply(const std::vector<double>& D, const std::vector<double>& r_, std::vector<double>& z_, int n, bool add) {
+    static void dinv_apply(const std::vector<double>& D, const std::vector<double>& r_, std::vector<double>& z_, int n, bool add, double ws) {
         #pragma omp parallel for schedule(static)
         for (int i = 0; i < n; ++i) {
             const double* d = &D[(size_t)i * 9]; const double* v = &r_[(size_t)i * 3];
-            for (int x = 0; x < 3; ++x) { const double s = d[3 * x] * v[0] + d[3 * x + 1] * v[1] + d[3 * x + 2] * v[2]; if (add) z_[(size_t)i * 3 + x] += s; else z_[(size_t)i * 3 + x] = s; }
+            for (int x = 0; x < 3; ++x) { const double s = ws * (d[3 * x] * v[0] + d[3 * x + 1] * v[1] + d[3 * x + 2] * v[2]); if (add) z_[(size_t)i * 3 + x] += s; else z_[(size_t)i * 3 + x] = s; }
         }
     }
     // rc = P^T v   (over R rows)
@@ -167,11 +187,11 @@ struct Hierarchy {
         const AmgLevel& L = sym->levels[l];
         static const int nu = getenv("TSGO_TWIN_NU") ? atoi(getenv("TSGO_TWIN_NU")) : tsgo::kCoarseSweeps;
         static const int gam = getenv("TSGO_TWIN_GAMMA") ? atoi(getenv("TSGO_TWIN_GAMMA")) : 1;
-        dinv_apply(Dinv[l], r[l], z[l], L.n, false);
+        dinv_apply(Dinv[l], r[l], z[l], L.n, false, omega[l]);
         for (int s = 1; s < nu; ++s) {
             spmv(L.A, A[l], z[l], res[l]);
             for (size_t k = 0; k < res[l].size(); ++k) res[l][k] = r[l][k] - res[l][k];
-            dinv_apply(Dinv[l], res[l], z[l], L.n, true);
+            dinv_apply(Dinv[l], res[l], z[l], L.n, true, omega[l]);
         }
         for (int g = 0; g < (l >= 2 ? gam : 1); ++g) {
             spmv(L.A, A[l], z[l], res[l]);
@@ -183,7 +203,7 @@ struct Hierarchy {
         for (int s = 0; s < nu; ++s) {
             spmv(L.A, A[l], z[l], res[l]);
             for (size_t k = 0; k < res[l].size(); ++k) res[l][k] = r[l][k] - res[l][k];
-            dinv_apply(Dinv[l], res[l], z[l], L.n, true);
+            dinv_apply(Dinv[l], res[l], z[l], L.n, true, omega[l]);
         }
     }
 };

@@ -131,7 +131,11 @@ struct Twin {
 
     // z = M^-1 r by one V(1,1) cycle (level 0 uses the implicit Schur product)
     void amg_apply() {
-        for (int i = 0; i < P; ++i) tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
+        const double w0 = hier.omega.empty() ? 1.0 : hier.omega[0];
+        for (int i = 0; i < P; ++i) {
+            tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
+            if (!amg.levels.empty()) for (int k = 0; k < 3; ++k) z[3 * (size_t)i + k] *= w0;
+        }
         if (amg.levels.empty()) return;
         schur_lm(z); schur_pose(z, s0);
         for (size_t k = 0; k < s0.size(); ++k) res0[k] = r[k] - s0[k];
@@ -142,7 +146,7 @@ struct Twin {
         for (int i = 0; i < P; ++i) {
             double d0, d1, d2;
             tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i] - s0[3 * (size_t)i], r[3 * (size_t)i + 1] - s0[3 * (size_t)i + 1], r[3 * (size_t)i + 2] - s0[3 * (size_t)i + 2], d0, d1, d2);
-            z[3 * (size_t)i] += d0; z[3 * (size_t)i + 1] += d1; z[3 * (size_t)i + 2] += d2;
+            z[3 * (size_t)i] += w0 * d0; z[3 * (size_t)i + 1] += w0 * d1; z[3 * (size_t)i + 2] += w0 * d2;
         }
     }
 

@@ -133,7 +133,7 @@ std::vector<int> find_diag(const BlockCsr& A) {
 
 // One coarsening step: level.A, level.agg, level.n_agg and xy are given; fills the rest and the
 // pattern of the next matrix.
-void coarsen(AmgLevel& L, const std::vector<double>& xy, BlockCsr& A_next, std::vector<double>& xy_next) {
+void coarsen(AmgLevel& L, const std::vector<double>& xy, BlockCsr& A_next, std::vector<double>& xy_next, bool smooth_p) {
     const int n = L.n, na = L.n_agg;
     L.diag = find_diag(L.A);
     // centroids, relative coordinates
@@ -153,8 +153,10 @@ void coarsen(AmgLevel& L, const std::vector<double>& xy, BlockCsr& A_next, std::
             for (int i = b; i < e; ++i) {
                 row.clear();
                 bool has_self = false;
-                for (int a = L.A.ptr[i]; a < L.A.ptr[i + 1]; ++a) { row.push_back({L.agg[L.A.col[a]], a, L.A.col[a]}); has_self |= L.agg[L.A.col[a]] == L.agg[i]; }
-                if (!has_self) row.push_back({L.agg[i], -1, -1});      // structurally missing diagonal
+                // smoothed prolongator: one block per aggregate the row touches, fed by the row's A blocks;
+                // plain (tentative) prolongator on the deep levels: the row's own aggregate only, no sources
+                if (smooth_p) for (int a = L.A.ptr[i]; a < L.A.ptr[i + 1]; ++a) { row.push_back({L.agg[L.A.col[a]], a, L.A.col[a]}); has_self |= L.agg[L.A.col[a]] == L.agg[i]; }
+                if (!has_self) row.push_back({L.agg[i], -1, -1});      // structurally missing diagonal / tentative prolongator
                 const size_t before = o.col.size();
                 emit_row(row, o);
                 for (size_t t = before; t < o.col.size(); ++t) o.flag.push_back(o.col[t] == L.agg[i] ? 1 : 0);
@@ -276,14 +278,15 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     for (int i = 0; i < P; ++i) { xy[2 * (size_t)i] = pr.pose_xyt[3 * (size_t)i]; xy[2 * (size_t)i + 1] = pr.pose_xyt[3 * (size_t)i + 1]; }
     L0.agg.resize(P);
     const int agg0 = getenv("TSGO_AGG0") ? atoi(getenv("TSGO_AGG0")) : kAggSize;
-    const int aggc = getenv("TSGO_AGGC") ? atoi(getenv("TSGO_AGGC")) : kAggSize;
+    const int aggc = getenv("TSGO_AGGC") ? atoi(getenv("TSGO_AGGC")) : kAggSizeCoarse;
+    const int smooth_levels = getenv("TSGO_SMOOTH_LEVELS") ? atoi(getenv("TSGO_SMOOTH_LEVELS")) : kSmoothLevels;
     for (int i = 0; i < P; ++i) L0.agg[i] = S.order[i] / agg0;
     L0.n_agg = (P + agg0 - 1) / agg0;
     AmgLevel cur = std::move(L0);
     for (;;) {
         if (cur.n <= kCoarsestMax) { S.A_last = cur.A; S.diag_last = find_diag(cur.A); break; }
         BlockCsr A_next; std::vector<double> xy_next;
-        coarsen(cur, xy, A_next, xy_next);
+        coarsen(cur, xy, A_next, xy_next, (int)S.levels.size() < smooth_levels);
         sw.lap("coarsen level");
         const int na = cur.n_agg;
         S.levels.push_back(std::move(cur));

@@ -20,10 +20,16 @@
 
 namespace tsgo {
 
-constexpr int kAggSize = 8;          // nodes per aggregate
+constexpr int kAggSize = 8;          // poses per aggregate on level 0
+constexpr int kAggSizeCoarse = 4;    // nodes per aggregate below (8 -> 4: 54 -> 32 PCG iterations at 100k poses, +1.7 ms setup)
+constexpr int kSmoothLevels = 99;    // levels whose prolongator is Jacobi-smoothed (the rest use the tentative one)
 constexpr int kCoarsestMax = 28;     // stop coarsening at <= this many block rows (dense inverse in LDS, <= 84 x 84)
 constexpr int kMaxPairDegree = 64;    // landmarks observed from more poses than this do not add off-diagonal level-0 blocks
 constexpr double kProlongOmega = 0.7;
+constexpr double kSmoother0Omega = 1.0; // smoother damping before the first estimate (level 0)
+constexpr double kSmootherOmega = 0.8;  // ... and on the coarse levels.  The working values are ESTIMATED per level from a power
+                                        // iteration on D^-1 A (omega = min(1, 1.6 / (1.05 rho))): smoothed Galerkin matrices reach
+                                        // rho = 2 ... 17, and omega * rho >= 2 makes the cycle indefinite (seen with fixed 0.8 / 1.0)
 constexpr int kCoarseSweeps = 2;      // block-Jacobi sweeps per side on the coarse levels: V(1,1) on level 0, V(2,2) below
                                       // (100k poses: 66 -> 53 PCG iterations for +30 us per iteration)
 

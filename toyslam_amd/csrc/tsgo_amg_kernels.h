@@ -161,6 +161,31 @@ __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __re
     out[(size_t)o * 9 + e] = acc;
 }
 
+// Same product for levels whose pair lists are long (smoothed Galerkin matrices get dense: hundreds of pairs
+// per output block): one wavefront per output block, lanes stride over the pairs and keep nine partial
+// sums each, xor-shuffle reduction at the end.  The nine-lane kernel above would walk such a list serially.
+template <typename T, int TRANS>
+__global__ __launch_bounds__(kBlock) void k_pair_gemm_wave(int n_out, const int* __restrict__ ptr, const int* __restrict__ px,
+                                                           const int* __restrict__ py, const T* __restrict__ X, const T* __restrict__ Y,
+                                                           T* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const int o = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (o >= n_out) return;
+    T acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = ptr[o] + lane; q < ptr[o + 1]; q += 64) {
+        T a[9], b[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) { a[m] = X[(size_t)px[q] * 9 + m]; b[m] = Y[(size_t)py[q] * 9 + m]; }
+        if (TRANS) m3_tmul_acc<T>(a, b, acc); else m3_mul_acc<T>(a, b, acc);
+    }
+#pragma unroll
+    for (int m = 0; m < 9; ++m) acc[m] = wave_sum<T>(acc[m]);
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < 9; ++m) out[(size_t)o * 9 + m] = acc[m];
+    }
+}
+
 // Dense inverse of the coarsest matrix in LDS (n <= 84), in-place Gauss-Jordan; SPD so no pivoting.
 // One workgroup of 1024 threads as a 32 x 32 tile walking the matrix.
 constexpr int kDenseThreads = 1024;
@@ -200,13 +225,14 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_inverse(int nb, const i
 // length of the dependent-load chain, so LPR lanes share one block row (one 3x3 block per lane per
 // trip, 72 contiguous bytes per lane) and finish with an LPR-lane xor-shuffle sum.
 
-// MODE 0: out = r - A z.   MODE 1: out = z + Dinv (r - A z)  (post-smoothing).
+// MODE 0: out = r - A z.   MODE 1: out = z + omega Dinv (r - A z)  (smoothing sweep).
+// MODE 2: out = Dinv A z  (power iteration for the smoother's damping).
 template <typename T, int LPR, int MODE>
 __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __restrict__ ptr, const int* __restrict__ col,
                                                           const T* __restrict__ A, const T* __restrict__ r, const T* __restrict__ z,
                                                           const T* __restrict__ Dinv, T* __restrict__ out,
-                                                          const CgState<T>* __restrict__ st) {
-    if (st->done) return;
+                                                          const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
+    if (MODE != 2 && st->done) return;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
@@ -217,13 +243,20 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
     }
     s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
     if (g < n && sub == 0) {
+        if (MODE == 2) {
+            const T* d = Dinv + (size_t)i * 9;
+            out[(size_t)i * 3] = d[0] * s0 + d[1] * s1 + d[2] * s2; out[(size_t)i * 3 + 1] = d[3] * s0 + d[4] * s1 + d[5] * s2;
+            out[(size_t)i * 3 + 2] = d[6] * s0 + d[7] * s1 + d[8] * s2;
+            return;
+        }
         const T e0 = r[(size_t)i * 3] - s0, e1 = r[(size_t)i * 3 + 1] - s1, e2 = r[(size_t)i * 3 + 2] - s2;
         if (MODE == 0) { out[(size_t)i * 3] = e0; out[(size_t)i * 3 + 1] = e1; out[(size_t)i * 3 + 2] = e2; }
         else {
+            const T omega = *omega_ptr;
             const T* d = Dinv + (size_t)i * 9;
-            out[(size_t)i * 3] = z[(size_t)i * 3] + d[0] * e0 + d[1] * e1 + d[2] * e2;
-            out[(size_t)i * 3 + 1] = z[(size_t)i * 3 + 1] + d[3] * e0 + d[4] * e1 + d[5] * e2;
-            out[(size_t)i * 3 + 2] = z[(size_t)i * 3 + 2] + d[6] * e0 + d[7] * e1 + d[8] * e2;
+            out[(size_t)i * 3] = z[(size_t)i * 3] + omega * (d[0] * e0 + d[1] * e1 + d[2] * e2);
+            out[(size_t)i * 3 + 1] = z[(size_t)i * 3 + 1] + omega * (d[3] * e0 + d[4] * e1 + d[5] * e2);
+            out[(size_t)i * 3 + 2] = z[(size_t)i * 3 + 2] + omega * (d[6] * e0 + d[7] * e1 + d[8] * e2);
         }
     }
 }
@@ -234,7 +267,7 @@ template <typename T, int LPR, int SUB>
 __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
                                                      const T* __restrict__ Rv, const T* __restrict__ va,
                                                      const T* __restrict__ vb, T* __restrict__ rc, const T* __restrict__ dinv_next,
-                                                     T* __restrict__ z_next, const CgState<T>* __restrict__ st) {
+                                                     T* __restrict__ z_next, const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
     if (st->done) return;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int a = g < n_agg ? g : n_agg - 1;
@@ -249,9 +282,11 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
     if (g < n_agg && sub == 0) {
         rc[(size_t)a * 3] = s0; rc[(size_t)a * 3 + 1] = s1; rc[(size_t)a * 3 + 2] = s2;
         if (dinv_next) {
+            const T omega = *omega_ptr;
             const T* d = dinv_next + (size_t)a * 9;
-            z_next[(size_t)a * 3] = d[0] * s0 + d[1] * s1 + d[2] * s2; z_next[(size_t)a * 3 + 1] = d[3] * s0 + d[4] * s1 + d[5] * s2;
-            z_next[(size_t)a * 3 + 2] = d[6] * s0 + d[7] * s1 + d[8] * s2;
+            z_next[(size_t)a * 3] = omega * (d[0] * s0 + d[1] * s1 + d[2] * s2);
+            z_next[(size_t)a * 3 + 1] = omega * (d[3] * s0 + d[4] * s1 + d[5] * s2);
+            z_next[(size_t)a * 3 + 2] = omega * (d[6] * s0 + d[7] * s1 + d[8] * s2);
         }
     }
 }
@@ -330,7 +365,7 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(int n, const T* __restri
 //   MODE 1: zc += Minv (r - s)       (post-smoothing; s = S zc from the implicit passes)
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void k_smooth0(int P, const T* __restrict__ minv, const T* __restrict__ r, const T* __restrict__ s,
-                                                    T* __restrict__ zc, const CgState<T>* __restrict__ st) {
+                                                    T* __restrict__ zc, const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
     if (st->done) return;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= P) return;
@@ -338,8 +373,24 @@ __global__ __launch_bounds__(kBlock) void k_smooth0(int P, const T* __restrict__
     if (MODE == 1) { e0 -= s[(size_t)i * 3]; e1 -= s[(size_t)i * 3 + 1]; e2 -= s[(size_t)i * 3 + 2]; }
     T z0, z1, z2;
     sym3_mul<T>(minv + (size_t)i * 6, e0, e1, e2, z0, z1, z2);
+    const T w = *omega_ptr;
     T* zr = zc + (size_t)i * kPoseRec;
-    if (MODE == 0) { zr[0] = z0; zr[1] = z1; zr[2] = z2; } else { zr[0] += z0; zr[1] += z1; zr[2] += z2; }
+    if (MODE == 0) { zr[0] = w * z0; zr[1] = w * z1; zr[2] = w * z2; } else { zr[0] += w * z0; zr[1] += w * z1; zr[2] += w * z2; }
+}
+
+// power iteration helpers: a fixed pseudo-random start vector and ||v||^2 partials
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_seed_vector(int n3, T* __restrict__ v) {
+    const int k = blockIdx.x * kBlock + threadIdx.x;
+    if (k < n3) v[k] = sin(T(0.37) * T(k)) + T(0.1);
+}
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_norm2(int n3, const T* __restrict__ v, T* __restrict__ part) {
+    __shared__ T red[kWavesPerBlock];
+    T g = 0;
+    for (int k = blockIdx.x * kBlock + threadIdx.x; k < n3; k += gridDim.x * kBlock) g += v[k] * v[k];
+    const T total = block_sum<T>(g, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = total;
 }
 
 // r^T D^-1 r partials (D = the 3x3 Schur diagonal): an SPD norm of the residual that does not involve the
@@ -367,7 +418,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
                                                     const T* __restrict__ rz_part, int n_part, const CgState<T>* __restrict__ st_in,
                                                     CgState<T>* __restrict__ st_out, T* __restrict__ r, T* __restrict__ p,
                                                     T* __restrict__ q, T* __restrict__ x, T* __restrict__ zc,
-                                                    const T* __restrict__ minv, T tol2, int max_iters) {
+                                                    const T* __restrict__ minv, const T* __restrict__ omega_ptr, T tol2, int max_iters) {
     __shared__ T red[kWavesPerBlock];
     const CgState<T> s = *st_in;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
@@ -400,8 +451,9 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
         // level-0 pre-smoothing of the NEXT V-cycle (zero initial guess): zc = Minv r
         T z0, z1, z2;
         sym3_mul<T>(minv + (size_t)i * 6, rr[0], rr[1], rr[2], z0, z1, z2);
+        const T w = *omega_ptr;
         T* zr = zc + (size_t)i * kPoseRec;
-        zr[0] = z0; zr[1] = z1; zr[2] = z2;
+        zr[0] = w * z0; zr[1] = w * z1; zr[2] = w * z2;
     }
     if (writer) { n.gamma_old = gamma; n.alpha_old = alpha; n.iters = s.iters + 1; *st_out = n; }
 }

@@ -71,12 +71,17 @@ struct IEngine {
     ncclComm_t comm = nullptr;
 };
 
+constexpr int kRhoSteps = 16, kRhoBlocks = 64, kRhoEvery = 8;   // smoother-damping estimate: power steps, partial sums, refresh period
+constexpr int kAmgIterCap = 400;        // a multigrid-preconditioned solve that needs more than this is treated as a
+                                        // failed preconditioner (stagnation) and repeated with block-Jacobi
+constexpr double kLongPairList = 24;    // Galerkin products with longer average lists use one wavefront per output block
 constexpr double kCertifySlack = 1e4;   // certificate: sqrt(r^T D^-1 r / b^T D^-1 b) <= slack * tol (norms differ by up to ~sqrt(cond))
 constexpr int kChunk = 16;   // PCG iterations per captured hipGraph (even: the state ring has 2 slots)
 constexpr int kChunkAmg = 2; // with the multigrid V-cycle an iteration is ~30 launches and a solve ~50 iterations
 
 template <typename T> struct DevLevel {      // device copy of one AmgLevel (host/amg.h) + its numeric arrays
     int n = 0, n_agg = 0, nnzA = 0, nnzP = 0, nnzT = 0, nnzNext = 0;
+    double pairs_T = 0, pairs_A = 0;      // average pair-list lengths of the two Galerkin products
     int *A_ptr = nullptr, *A_col = nullptr, *A_row = nullptr, *diag = nullptr;
     int *P_ptr = nullptr, *P_col = nullptr, *P_row = nullptr, *p_self = nullptr, *ps_ptr = nullptr, *ps_x = nullptr, *ps_y = nullptr;
     int *R_ptr = nullptr, *R_col = nullptr, *r_to_p = nullptr, *p_to_r = nullptr;
@@ -113,6 +118,10 @@ template <typename T> struct Engine : IEngine {
     int *last_ptr = nullptr, *last_col = nullptr; int nb_last = 0, nnz_last = 0;
     T *A_last = nullptr, *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr;
     double ms_amg_symbolic = 0;
+    T *omega_dev = nullptr, *one_dev = nullptr, *pw_a = nullptr, *pw_b = nullptr, *rho_part = nullptr;
+    T* h_rho = nullptr;                 // pinned
+    std::vector<double> omega_host;    // smoother damping per level (diagnostics)
+    int lin_count = 0;
     int coarse_sweeps = kCoarseSweeps;
 
     explicit Engine(const tsgo_config& c) : cfg(c) {
@@ -184,6 +193,7 @@ template <typename T> struct Engine : IEngine {
         for (size_t l = 0; l < amg.levels.size(); ++l) {
             const AmgLevel& L = amg.levels[l]; DevLevel<T>& D = lv[l];
             D.n = L.n; D.n_agg = L.n_agg; D.nnzA = L.A.nnz(); D.nnzP = L.P.nnz(); D.nnzT = L.T.nnz(); D.nnzNext = (int)L.a_src.ptr.size() - 1;
+            D.pairs_T = (double)L.t_src.x.size() / std::max(1, D.nnzT); D.pairs_A = (double)L.a_src.x.size() / std::max(1, D.nnzNext);
             UP(D.A_ptr, L.A.ptr); UP(D.A_col, L.A.col); UP(D.A_row, rows_of(L.A)); UP(D.diag, L.diag);
             UP(D.P_ptr, L.P.ptr); UP(D.P_col, L.P.col); UP(D.P_row, rows_of(L.P)); UP(D.p_self, L.p_self);
             UP(D.ps_ptr, L.p_src.ptr); UP(D.ps_x, L.p_src.x); UP(D.ps_y, L.p_src.y);
@@ -217,6 +227,19 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&r_last, (size_t)nb_last * 3)) return rc;
         if (int rc = dalloc(&z_last, (size_t)nb_last * 3)) return rc;
         if (int rc = dalloc(&rzpart, (size_t)nbP)) return rc;
+        if (int rc = dalloc(&omega_dev, 16)) return rc;
+        if (int rc = dalloc(&pw_a, (size_t)pr.P * 3)) return rc;
+        if (int rc = dalloc(&pw_b, (size_t)pr.P * 3)) return rc;
+        if (int rc = dalloc(&rho_part, 16 * 2 * kRhoBlocks)) return rc;
+        if (lv.size() > 16) return set_error(-2, "tsgo_set_graph: too many multigrid levels");
+        {
+            std::vector<T> init(16, (T)kSmootherOmega); init[0] = (T)kSmoother0Omega;
+            HIP_OK(hipMemcpy(omega_dev, init.data(), 16 * sizeof(T), hipMemcpyHostToDevice));
+            omega_host.assign(lv.size(), kSmootherOmega); omega_host[0] = kSmoother0Omega;
+        }
+        if (h_rho) (void)hipHostFree(h_rho);
+        HIP_OK(hipHostMalloc((void**)&h_rho, sizeof(T) * 16 * 2 * kRhoBlocks));
+        lin_count = 0;
         return 0;
     }
 
@@ -286,6 +309,8 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipMemset(dl, 0, (size_t)std::max(L, 1) * 2 * sizeof(T)));
         for (int k = 0; k < 2; ++k) { if (int rc = dalloc(&gpart[k], nbC)) return rc; if (int rc = dalloc(&st[k], 1)) return rc; }
         if (int rc = dalloc(&npart, (size_t)nbC + std::max(nbL, 1))) return rc;
+        if (int rc = dalloc(&one_dev, 1)) return rc;
+        { const T one = 1; HIP_OK(hipMemcpy(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)); }
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
         HIP_OK(hipDeviceSynchronize());
@@ -305,7 +330,7 @@ template <typename T> struct Engine : IEngine {
         LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18);
     }
     void launch_finalize() {
-        hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0]);
+        hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0], (const T*)(amg_on ? omega_dev : one_dev));
     }
     void launch_matvec(int slot, bool with_rz = false) {   // S * (vector in zc) -> sbuf, dot partials behind it
         if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, tvec, st[slot], T(0), dl, npart);
@@ -325,8 +350,10 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL((k_block_inv<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.diag, (const T*)L.A, L.Dinv);
             hipLaunchKernelGGL((k_prolongator<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, L.P_row, L.p_self, L.ps_ptr, L.ps_x, L.ps_y,
                                (const T*)L.A, (const T*)L.Dinv, (const T*)L.rel, (T)kProlongOmega, L.P, L.p_to_r, L.Rv);
-            hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for((L.nnzT + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const T*)L.A, (const T*)L.P, L.Tv);
-            hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.nnzNext + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const T*)L.P, (const T*)L.Tv, Anext);
+            if (L.pairs_T > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 0>), dim3(grid_for(L.nnzT, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const T*)L.A, (const T*)L.P, L.Tv);
+            else hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for((L.nnzT + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const T*)L.A, (const T*)L.P, L.Tv);
+            if (L.pairs_A > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1>), dim3(grid_for(L.nnzNext, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const T*)L.P, (const T*)L.Tv, Anext);
+            else hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.nnzNext + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const T*)L.P, (const T*)L.Tv, Anext);
         }
         hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kDenseThreads), 0, stream, nb_last, last_ptr, last_col, (const T*)A_last, inv_last);
     }
@@ -350,6 +377,44 @@ template <typename T> struct Engine : IEngine {
         }
     }
 
+    // Damping of the block-Jacobi smoother per level from a power iteration on D^-1 A (12 steps): the V-cycle
+    // is a symmetric positive definite preconditioner only while omega * rho(D^-1 A) < 2, and smoothed Galerkin
+    // matrices reach rho = 2.1 ... 3.4 (measured on the CPU twin).  omega = min(1, 1.6 / (1.05 rho)).
+    int estimate_damping() {
+        const size_t nl = lv.size();
+        for (size_t l = 0; l < nl; ++l) {
+            DevLevel<T>& L = lv[l];
+            T* a = l == 0 ? pw_a : L.res; T* b = l == 0 ? pw_b : L.z2;
+            const int n3 = L.n * 3;
+            hipLaunchKernelGGL((k_seed_vector<T>), dim3(grid_for(n3)), dim3(kBlock), 0, stream, n3, a);
+            const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
+            for (int it = 0; it < kRhoSteps; ++it) {
+                LAUNCH_LPR(lprA, k_bcsr_residual, 2, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)a, (const T*)a, (const T*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]);
+                std::swap(a, b);
+            }
+            // a = v_K, b = v_{K-1}
+            hipLaunchKernelGGL((k_norm2<T>), dim3(kRhoBlocks), dim3(kBlock), 0, stream, n3, (const T*)a, rho_part + (2 * l) * kRhoBlocks);
+            hipLaunchKernelGGL((k_norm2<T>), dim3(kRhoBlocks), dim3(kBlock), 0, stream, n3, (const T*)b, rho_part + (2 * l + 1) * kRhoBlocks);
+        }
+        HIP_OK(hipMemcpyAsync(h_rho, rho_part, sizeof(T) * 2 * nl * kRhoBlocks, hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        std::vector<T> om(16, (T)kSmootherOmega);
+        for (size_t l = 0; l < nl; ++l) {
+            double nk = 0, nk1 = 0;
+            for (int k = 0; k < kRhoBlocks; ++k) { nk += (double)h_rho[(2 * l) * kRhoBlocks + k]; nk1 += (double)h_rho[(2 * l + 1) * kRhoBlocks + k]; }
+            double w = kSmootherOmega;
+            if (nk1 > 0 && nk > 0 && std::isfinite(nk) && std::isfinite(nk1)) {
+                const double rho = 1.05 * std::sqrt(nk / nk1);
+                w = std::min(1.0, 1.6 / rho);
+            }
+            om[l] = (T)w; omega_host[l] = w;
+        }
+        if (cfg.verbose || getenv("TSGO_VERBOSE")) { std::fprintf(stderr, "[tsgo] smoother damping per level:"); for (size_t l = 0; l < nl; ++l) std::fprintf(stderr, " %.3f", omega_host[l]); std::fprintf(stderr, "\n"); }
+        HIP_OK(hipMemcpyAsync(omega_dev, om.data(), 16 * sizeof(T), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        return 0;
+    }
+
     // zc[.][0..2] = V(1,1)-cycle(r).  On entry zc already holds the level-0 pre-smoothing Minv r
     // (written by pose_finalize / k_cg_step).  Level l >= 1 keeps r, z (pre-smoothed by the restriction
     // above it), res and the post-smoothed result z2.
@@ -360,7 +425,7 @@ template <typename T> struct Engine : IEngine {
         {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, (const T*)r, (const T*)sbuf, lv[1].r, (const T*)lv[1].Dinv, lv[1].z, s);
+            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, (const T*)r, (const T*)sbuf, lv[1].r, (const T*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
         }
         // coarse levels: V(nu,nu) with nu = coarse_sweeps block-Jacobi sweeps (the first pre-sweep comes fused
         // with the restriction above).  The current iterate alternates between L.z and L.z2; it ends in L.z2.
@@ -370,13 +435,13 @@ template <typename T> struct Engine : IEngine {
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
             T* cur = L.z; T* oth = L.z2;
             for (int sw = 1; sw < nu; ++sw) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, oth, s);
+                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, oth, (const T*)(omega_dev + l), s);
                 std::swap(cur, oth);
             }
-            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, L.res, s);
+            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, L.res, (const T*)(omega_dev + l), s);
             if (l + 1 < nl) {
                 const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const T*)lv[l + 1].Dinv, lv[l + 1].z, s);
+                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const T*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
             }
         }
         // iterate of level l after the down pass: L.z when nu is odd, L.z2 when even
@@ -389,7 +454,7 @@ template <typename T> struct Engine : IEngine {
         } else {        // only level 0 above the dense level: residual r - S z is restricted from (r, sbuf)
             DevLevel<T>& L = lv[0];
             hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv,
-                               (const T*)r, (const T*)sbuf, r_last, (const T*)nullptr, (T*)nullptr, s);
+                               (const T*)r, (const T*)sbuf, r_last, (const T*)nullptr, (T*)nullptr, (const T*)one_dev, s);
             hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
         }
         for (size_t l = nl - 1; l >= 1; --l) {
@@ -398,19 +463,19 @@ template <typename T> struct Engine : IEngine {
             if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, cur, 3, s);
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
             for (int sw = 0; sw < nu; ++sw) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, oth, s);
+                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, oth, (const T*)(omega_dev + l), s);
                 std::swap(cur, oth);
             }
             // nu post-sweeps after nu-1 pre-swaps: the result sits in L.z2 for every nu (odd+odd / even+even swaps)
         }
         launch_prolong(lv[0], nl > 1 ? (const T*)lv[1].z2 : (const T*)z_last, zc, kPoseRec, s);
         launch_matvec(slot);
-        hipLaunchKernelGGL((k_smooth0<T, 1>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, s);
+        hipLaunchKernelGGL((k_smooth0<T, 1>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, (const T*)omega_dev, s);
     }
     void launch_cg_step(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
         hipLaunchKernelGGL((k_cg_step<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)(sbuf + (size_t)pr.P * 3), (const T*)rzpart, nbP,
-                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, tol2, cfg.pcg_max_iters);
+                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, (const T*)omega_dev, tol2, std::min(cfg.pcg_max_iters, kAmgIterCap));
     }
     // one PCG iteration reading state slot `slot`, writing slot^1
     void launch_iteration(int slot) {
@@ -444,7 +509,13 @@ template <typename T> struct Engine : IEngine {
         launch_lin();
         if (int rc = allreduce(part, (size_t)pr.P * 18 + nbP)) return rc;
         launch_finalize();
-        if (amg_on) launch_amg_setup();
+        if (amg_on) {
+            launch_amg_setup();
+            if (lin_count++ % kRhoEvery == 0) {
+                if (int rc = estimate_damping()) return rc;
+                launch_finalize();        // zc = omega_0 Minv r with the fresh omega_0
+            }
+        }
         HIP_OK(hipMemcpyAsync(h_scratch, part + (size_t)pr.P * 18, sizeof(T) * nbP, hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
         double s = 0;
@@ -472,6 +543,7 @@ template <typename T> struct Engine : IEngine {
             if (getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] certificate: sqrt(rDr/bDb) = %.3e (tol %.1e, limit %.1e), %d iterations\n", std::sqrt(num / den), cfg.pcg_rel_tol, lim, *iters);
             if (!(num <= lim * lim * den)) *fail = 1;
         }
+        if (*fail == 2 && amg_on && *iters >= std::min(cfg.pcg_max_iters, kAmgIterCap) && cfg.pcg_max_iters > kAmgIterCap) *fail = 1;
         if (*fail == 1 && amg_on) {
             ++n_fallbacks;
             const bool keep = amg_on; hipGraphExec_t g = cg_graph;
@@ -503,7 +575,7 @@ template <typename T> struct Engine : IEngine {
             HIP_OK(hipMemcpyAsync(h_state, st[0], sizeof(CgState<T>), hipMemcpyDeviceToHost, stream));
             HIP_OK(hipStreamSynchronize(stream));
             if (h_state->done) break;
-            if (launched > cfg.pcg_max_iters + 2 * ch) return set_error(-20, "PCG did not terminate");
+            if (launched > std::max(cfg.pcg_max_iters, kAmgIterCap) + 2 * ch) return set_error(-20, "PCG did not terminate");
         }
         *iters = h_state->iters; *fail = h_state->fail;
         predicted_cg = h_state->iters;

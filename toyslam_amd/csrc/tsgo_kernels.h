@@ -246,7 +246,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __rest
                                                           T* __restrict__ dp, T* __restrict__ minv, T* __restrict__ r,
                                                           T* __restrict__ p, T* __restrict__ q, T* __restrict__ x,
                                                           T* __restrict__ zc, T* __restrict__ gpart,
-                                                          CgState<T>* __restrict__ st0) {
+                                                          CgState<T>* __restrict__ st0, const T* __restrict__ omega_ptr) {
     __shared__ T red[kWavesPerBlock];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     T g = 0;
@@ -265,7 +265,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __rest
 #pragma unroll
         for (int k = 0; k < 3; ++k) { p[(size_t)i * 3 + k] = 0; q[(size_t)i * 3 + k] = 0; x[(size_t)i * 3 + k] = 0; }
         T* zr = zc + (size_t)i * kPoseRec;
-        zr[0] = z0; zr[1] = z1; zr[2] = z2; zr[3] = ps[(size_t)i * 4 + 2]; zr[4] = ps[(size_t)i * 4 + 3];
+        const T w = *omega_ptr;    // 1 for block-Jacobi PCG; the level-0 smoother damping under the multigrid cycle
+        zr[0] = w * z0; zr[1] = w * z1; zr[2] = w * z2; zr[3] = ps[(size_t)i * 4 + 2]; zr[4] = ps[(size_t)i * 4 + 3];
         g = r0 * z0 + r1 * z1 + r2 * z2;
     }
     const T total = block_sum<T>(g, red);

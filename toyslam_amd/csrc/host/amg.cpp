@@ -277,8 +277,16 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     std::vector<double> xy((size_t)P * 2);
     for (int i = 0; i < P; ++i) { xy[2 * (size_t)i] = pr.pose_xyt[3 * (size_t)i]; xy[2 * (size_t)i + 1] = pr.pose_xyt[3 * (size_t)i + 1]; }
     L0.agg.resize(P);
-    const int agg0 = getenv("TSGO_AGG0") ? atoi(getenv("TSGO_AGG0")) : kAggSize;
-    const int aggc = getenv("TSGO_AGGC") ? atoi(getenv("TSGO_AGGC")) : kAggSizeCoarse;
+    // aggregate size per level; research override: TSGO_AGG_LIST="8,4,4,8" (last entry repeats) or TSGO_AGG0 / TSGO_AGGC
+    std::vector<int> agg_list;
+    if (const char* e = getenv("TSGO_AGG_LIST")) { for (const char* q = e; *q;) { agg_list.push_back(std::max(2, atoi(q))); while (*q && *q != ',') ++q; if (*q == ',') ++q; } }
+    if (agg_list.empty()) {
+        agg_list.push_back(getenv("TSGO_AGG0") ? atoi(getenv("TSGO_AGG0")) : kAggSize);
+        if (getenv("TSGO_AGGC")) agg_list.push_back(atoi(getenv("TSGO_AGGC")));
+        else for (int m : kAggSizesBelow) agg_list.push_back(m);
+    }
+    auto agg_at = [&](size_t l) { return agg_list[std::min(l, agg_list.size() - 1)]; };
+    const int agg0 = agg_at(0);
     const int smooth_levels = getenv("TSGO_SMOOTH_LEVELS") ? atoi(getenv("TSGO_SMOOTH_LEVELS")) : kSmoothLevels;
     for (int i = 0; i < P; ++i) L0.agg[i] = S.order[i] / agg0;
     L0.n_agg = (P + agg0 - 1) / agg0;
@@ -293,6 +301,7 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
         cur = AmgLevel();
         cur.n = na; cur.A = std::move(A_next);
         cur.agg.resize(na);
+        const int aggc = agg_at(S.levels.size());
         for (int a = 0; a < na; ++a) cur.agg[a] = a / aggc;     // aggregates are numbered along the trajectory
         cur.n_agg = (na + aggc - 1) / aggc;
         xy = std::move(xy_next);

@@ -21,7 +21,7 @@
 namespace tsgo {
 
 constexpr int kAggSize = 8;          // poses per aggregate on level 0
-constexpr int kAggSizeCoarse = 4;    // nodes per aggregate below (8 -> 4: 54 -> 32 PCG iterations at 100k poses, +1.7 ms setup)
+constexpr int kAggSizesBelow[] = {4, 4, 8};   // nodes per aggregate on levels 1, 2, 3+ (the last repeats)
 constexpr int kSmoothLevels = 99;    // levels whose prolongator is Jacobi-smoothed (the rest use the tentative one)
 constexpr int kCoarsestMax = 28;     // stop coarsening at <= this many block rows (dense inverse in LDS, <= 84 x 84)
 constexpr int kMaxPairDegree = 64;    // landmarks observed from more poses than this do not add off-diagonal level-0 blocks

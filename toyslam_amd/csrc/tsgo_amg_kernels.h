@@ -12,19 +12,29 @@
 
 namespace tsgo {
 
+// Storage type of the multigrid hierarchy (A_l, D^-1, P, R, A P).  The hierarchy only preconditions: PCG
+// converges to the same f64 solution with operators rounded to f32, and every setup/cycle kernel that is
+// bound by gathered 72-byte blocks moves half the bytes.  Sums are accumulated in the vector type T.
+#ifdef TSGO_HIER_F64
+template <typename T> struct Hier { using type = T; };
+#else
+template <typename T> struct Hier { using type = float; };
+#endif
+template <typename T> using HT = typename Hier<T>::type;
+
 constexpr int kDenseMax = 84;            // coarsest matrix is at most 84 x 84 (host/amg.h: kCoarsestMax * 3)
 
-template <typename T> __device__ __forceinline__ void m3_mul_acc(const T* a, const T* b, T* c) {
+template <typename T, typename A, typename B> __device__ __forceinline__ void m3_mul_acc(const A* a, const B* b, T* c) {
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) c[3 * i + j] += a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+        for (int j = 0; j < 3; ++j) c[3 * i + j] += T(a[3 * i]) * T(b[j]) + T(a[3 * i + 1]) * T(b[3 + j]) + T(a[3 * i + 2]) * T(b[6 + j]);
 }
-template <typename T> __device__ __forceinline__ void m3_tmul_acc(const T* a, const T* b, T* c) {   // c += a^T b
+template <typename T, typename A, typename B> __device__ __forceinline__ void m3_tmul_acc(const A* a, const B* b, T* c) {   // c += a^T b
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) c[3 * i + j] += a[i] * b[j] + a[3 + i] * b[3 + j] + a[6 + i] * b[6 + j];
+        for (int j = 0; j < 3; ++j) c[3 * i + j] += T(a[i]) * T(b[j]) + T(a[3 + i]) * T(b[3 + j]) + T(a[6 + i]) * T(b[6 + j]);
 }
 template <typename T> __device__ __forceinline__ void m3_inv(const T* m, T* o) {
     const T c00 = m[4] * m[8] - m[5] * m[7], c01 = m[5] * m[6] - m[3] * m[8], c02 = m[3] * m[7] - m[4] * m[6];
@@ -45,11 +55,11 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
                                                          const uint32_t* __restrict__ slot_k, const int* __restrict__ optr,
                                                          const uint32_t* __restrict__ oslot, Table<T> tb, const T* __restrict__ od_dyn,
                                                          size_t od_slots, const T* __restrict__ lmrec, const T* __restrict__ ps,
-                                                         const T* __restrict__ part, T* __restrict__ A) {
+                                                         const T* __restrict__ part, HT<T>* __restrict__ A) {
     const int b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= nnz) return;
     const int i = blk_row[b], k = blk_col[b];
-    T* o = A + (size_t)b * 9;
+    HT<T>* o = A + (size_t)b * 9;
     if (i == k) {
         const T* p = part + (size_t)i * 18;
         const T m0 = p[0] - p[9], m1 = p[1] - p[10], m2 = p[2] - p[11], m3 = p[3] - p[12], m4 = p[4] - p[13], m5 = p[5] - p[14];
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
 }
 
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_block_inv(int n, const int* __restrict__ diag, const T* __restrict__ A, T* __restrict__ Dinv) {
+__global__ __launch_bounds__(kBlock) void k_block_inv(int n, const int* __restrict__ diag, const HT<T>* __restrict__ A, HT<T>* __restrict__ Dinv) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= n) return;
     T m[9], o[9];
@@ -104,8 +114,8 @@ __global__ __launch_bounds__(kBlock) void k_block_inv(int n, const int* __restri
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __restrict__ p_row, const int* __restrict__ p_self,
                                                         const int* __restrict__ sptr, const int* __restrict__ sx, const int* __restrict__ sy,
-                                                        const T* __restrict__ A, const T* __restrict__ Dinv, const T* __restrict__ rel,
-                                                        T omega, T* __restrict__ P, const int* __restrict__ p_to_r, T* __restrict__ Rv) {
+                                                        const HT<T>* __restrict__ A, const HT<T>* __restrict__ Dinv, const T* __restrict__ rel,
+                                                        T omega, HT<T>* __restrict__ P, const int* __restrict__ p_to_r, HT<T>* __restrict__ Rv) {
     const int pb = blockIdx.x * kBlock + threadIdx.x;
     if (pb >= nnzP) return;
     const int i = p_row[pb];
@@ -133,7 +143,7 @@ __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __r
     for (int m = 0; m < 9; ++m) P[(size_t)pb * 9 + m] = o[m];
     // the same block transposed, stored in the order the restriction walks it (rows of R = P^T):
     // reading P through an index there cost 2.7x the bytes (profiles/r01c: 88 MB for a 33 MB operator)
-    T* rt = Rv + (size_t)p_to_r[pb] * 9;
+    HT<T>* rt = Rv + (size_t)p_to_r[pb] * 9;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -145,8 +155,8 @@ __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __r
 // touch the same two 72-byte blocks, so the loads coalesce), 7 output blocks per wavefront.
 template <typename T, int TRANS>
 __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __restrict__ ptr, const int* __restrict__ px,
-                                                      const int* __restrict__ py, const T* __restrict__ X, const T* __restrict__ Y,
-                                                      T* __restrict__ out) {
+                                                      const int* __restrict__ py, const HT<T>* __restrict__ X, const HT<T>* __restrict__ Y,
+                                                      HT<T>* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     if (lane >= 63) return;
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
@@ -154,9 +164,9 @@ __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __re
     if (o >= n_out) return;
     T acc = 0;
     for (int q = ptr[o]; q < ptr[o + 1]; ++q) {
-        const T* a = X + (size_t)px[q] * 9; const T* b = Y + (size_t)py[q] * 9;
-        if (TRANS) acc += a[i] * b[j] + a[3 + i] * b[3 + j] + a[6 + i] * b[6 + j];
-        else acc += a[3 * i] * b[j] + a[3 * i + 1] * b[3 + j] + a[3 * i + 2] * b[6 + j];
+        const HT<T>* a = X + (size_t)px[q] * 9; const HT<T>* b = Y + (size_t)py[q] * 9;
+        if (TRANS) acc += T(a[i]) * T(b[j]) + T(a[3 + i]) * T(b[3 + j]) + T(a[6 + i]) * T(b[6 + j]);
+        else acc += T(a[3 * i]) * T(b[j]) + T(a[3 * i + 1]) * T(b[3 + j]) + T(a[3 * i + 2]) * T(b[6 + j]);
     }
     out[(size_t)o * 9 + e] = acc;
 }
@@ -166,8 +176,8 @@ __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __re
 // sums each, xor-shuffle reduction at the end.  The nine-lane kernel above would walk such a list serially.
 template <typename T, int TRANS>
 __global__ __launch_bounds__(kBlock) void k_pair_gemm_wave(int n_out, const int* __restrict__ ptr, const int* __restrict__ px,
-                                                           const int* __restrict__ py, const T* __restrict__ X, const T* __restrict__ Y,
-                                                           T* __restrict__ out) {
+                                                           const int* __restrict__ py, const HT<T>* __restrict__ X, const HT<T>* __restrict__ Y,
+                                                           HT<T>* __restrict__ out) {
     const int lane = threadIdx.x & 63;
     const int o = (blockIdx.x * kBlock + threadIdx.x) >> 6;
     if (o >= n_out) return;
@@ -191,7 +201,7 @@ __global__ __launch_bounds__(kBlock) void k_pair_gemm_wave(int n_out, const int*
 constexpr int kDenseThreads = 1024;
 template <typename T>
 __global__ __launch_bounds__(kDenseThreads) void k_dense_inverse(int nb, const int* __restrict__ ptr, const int* __restrict__ col,
-                                                                 const T* __restrict__ A, T* __restrict__ inv) {
+                                                                 const HT<T>* __restrict__ A, T* __restrict__ inv) {
     __shared__ T M[kDenseMax * kDenseMax];
     __shared__ T colk[kDenseMax];
     const int n = nb * 3;
@@ -229,22 +239,22 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_inverse(int nb, const i
 // MODE 2: out = Dinv A z  (power iteration for the smoother's damping).
 template <typename T, int LPR, int MODE>
 __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __restrict__ ptr, const int* __restrict__ col,
-                                                          const T* __restrict__ A, const T* __restrict__ r, const T* __restrict__ z,
-                                                          const T* __restrict__ Dinv, T* __restrict__ out,
+                                                          const HT<T>* __restrict__ A, const T* __restrict__ r, const T* __restrict__ z,
+                                                          const HT<T>* __restrict__ Dinv, T* __restrict__ out,
                                                           const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
     if (MODE != 2 && st->done) return;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
     for (int a = ptr[i] + sub; a < ptr[i + 1]; a += LPR) {
-        const T* b = A + (size_t)a * 9; const T* v = z + (size_t)col[a] * 3;
+        const HT<T>* b = A + (size_t)a * 9; const T* v = z + (size_t)col[a] * 3;
         const T v0 = v[0], v1 = v[1], v2 = v[2];
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
     s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
     if (g < n && sub == 0) {
         if (MODE == 2) {
-            const T* d = Dinv + (size_t)i * 9;
+            const HT<T>* d = Dinv + (size_t)i * 9;
             out[(size_t)i * 3] = d[0] * s0 + d[1] * s1 + d[2] * s2; out[(size_t)i * 3 + 1] = d[3] * s0 + d[4] * s1 + d[5] * s2;
             out[(size_t)i * 3 + 2] = d[6] * s0 + d[7] * s1 + d[8] * s2;
             return;
@@ -253,7 +263,7 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
         if (MODE == 0) { out[(size_t)i * 3] = e0; out[(size_t)i * 3 + 1] = e1; out[(size_t)i * 3 + 2] = e2; }
         else {
             const T omega = *omega_ptr;
-            const T* d = Dinv + (size_t)i * 9;
+            const HT<T>* d = Dinv + (size_t)i * 9;
             out[(size_t)i * 3] = z[(size_t)i * 3] + omega * (d[0] * e0 + d[1] * e1 + d[2] * e2);
             out[(size_t)i * 3 + 1] = z[(size_t)i * 3 + 1] + omega * (d[3] * e0 + d[4] * e1 + d[5] * e2);
             out[(size_t)i * 3 + 2] = z[(size_t)i * 3 + 2] + omega * (d[6] * e0 + d[7] * e1 + d[8] * e2);
@@ -265,15 +275,15 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
 // z_next = Dinv_next rc in the same pass.  SUB: v = a - b (level 0: r - S z, never materialised).
 template <typename T, int LPR, int SUB>
 __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
-                                                     const T* __restrict__ Rv, const T* __restrict__ va,
-                                                     const T* __restrict__ vb, T* __restrict__ rc, const T* __restrict__ dinv_next,
+                                                     const HT<T>* __restrict__ Rv, const T* __restrict__ va,
+                                                     const T* __restrict__ vb, T* __restrict__ rc, const HT<T>* __restrict__ dinv_next,
                                                      T* __restrict__ z_next, const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
     if (st->done) return;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int a = g < n_agg ? g : n_agg - 1;
     T s0 = 0, s1 = 0, s2 = 0;
     for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += LPR) {
-        const T* b = Rv + (size_t)rb * 9; const size_t i = (size_t)rcol[rb] * 3;
+        const HT<T>* b = Rv + (size_t)rb * 9; const size_t i = (size_t)rcol[rb] * 3;
         T x0 = va[i], x1 = va[i + 1], x2 = va[i + 2];
         if (SUB) { x0 -= vb[i]; x1 -= vb[i + 1]; x2 -= vb[i + 2]; }
         s0 += b[0] * x0 + b[1] * x1 + b[2] * x2; s1 += b[3] * x0 + b[4] * x1 + b[5] * x2; s2 += b[6] * x0 + b[7] * x1 + b[8] * x2;
@@ -283,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
         rc[(size_t)a * 3] = s0; rc[(size_t)a * 3 + 1] = s1; rc[(size_t)a * 3 + 2] = s2;
         if (dinv_next) {
             const T omega = *omega_ptr;
-            const T* d = dinv_next + (size_t)a * 9;
+            const HT<T>* d = dinv_next + (size_t)a * 9;
             z_next[(size_t)a * 3] = omega * (d[0] * s0 + d[1] * s1 + d[2] * s2);
             z_next[(size_t)a * 3 + 1] = omega * (d[3] * s0 + d[4] * s1 + d[5] * s2);
             z_next[(size_t)a * 3 + 2] = omega * (d[6] * s0 + d[7] * s1 + d[8] * s2);
@@ -294,14 +304,14 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
 // z_i += sum_a P_ia e_a; z has row stride `zs` (3 on coarse levels, kPoseRec for zc)
 template <typename T, int LPR>
 __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __restrict__ pptr, const int* __restrict__ pcol,
-                                                        const T* __restrict__ P, const T* __restrict__ e, T* __restrict__ z, int zs,
+                                                        const HT<T>* __restrict__ P, const T* __restrict__ e, T* __restrict__ z, int zs,
                                                         const CgState<T>* __restrict__ st) {
     if (st->done) return;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
     for (int pb = pptr[i] + sub; pb < pptr[i + 1]; pb += LPR) {
-        const T* b = P + (size_t)pb * 9; const T* v = e + (size_t)pcol[pb] * 3;
+        const HT<T>* b = P + (size_t)pb * 9; const T* v = e + (size_t)pcol[pb] * 3;
         const T v0 = v[0], v1 = v[1], v2 = v[2];
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
@@ -314,8 +324,8 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
 // prolong the correction back (4 lanes per row).
 template <typename T>
 __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
-                                                               const T* __restrict__ Rv, const int* __restrict__ pptr,
-                                                               const int* __restrict__ pcol, const T* __restrict__ P, const T* __restrict__ res,
+                                                               const HT<T>* __restrict__ Rv, const int* __restrict__ pptr,
+                                                               const int* __restrict__ pcol, const HT<T>* __restrict__ P, const T* __restrict__ res,
                                                                const T* __restrict__ inv, T* __restrict__ z, const CgState<T>* __restrict__ st) {
     if (st->done) return;
     __shared__ T rc[kDenseMax], zc_[kDenseMax];
@@ -324,7 +334,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg,
         T s0 = 0, s1 = 0, s2 = 0;
         if (a < n_agg)
             for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += 32) {
-                const T* b = Rv + (size_t)rb * 9; const size_t i = (size_t)rcol[rb] * 3;
+                const HT<T>* b = Rv + (size_t)rb * 9; const size_t i = (size_t)rcol[rb] * 3;
                 const T x0 = res[i], x1 = res[i + 1], x2 = res[i + 2];
                 s0 += b[0] * x0 + b[1] * x1 + b[2] * x2; s1 += b[3] * x0 + b[4] * x1 + b[5] * x2; s2 += b[6] * x0 + b[7] * x1 + b[8] * x2;
             }
@@ -340,7 +350,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg,
         T s0 = 0, s1 = 0, s2 = 0;
         if (i < n)
             for (int pb = pptr[i] + sub; pb < pptr[i + 1]; pb += 4) {
-                const T* b = P + (size_t)pb * 9; const T* v = zc_ + pcol[pb] * 3;
+                const HT<T>* b = P + (size_t)pb * 9; const T* v = zc_ + pcol[pb] * 3;
                 s0 += b[0] * v[0] + b[1] * v[1] + b[2] * v[2]; s1 += b[3] * v[0] + b[4] * v[1] + b[5] * v[2]; s2 += b[6] * v[0] + b[7] * v[1] + b[8] * v[2];
             }
         s0 = group_sum<T, 4>(s0); s1 = group_sum<T, 4>(s1); s2 = group_sum<T, 4>(s2);

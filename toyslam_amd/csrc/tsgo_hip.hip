@@ -86,7 +86,9 @@ template <typename T> struct DevLevel {      // device copy of one AmgLevel (hos
     int *P_ptr = nullptr, *P_col = nullptr, *P_row = nullptr, *p_self = nullptr, *ps_ptr = nullptr, *ps_x = nullptr, *ps_y = nullptr;
     int *R_ptr = nullptr, *R_col = nullptr, *r_to_p = nullptr, *p_to_r = nullptr;
     int *ts_ptr = nullptr, *ts_x = nullptr, *ts_y = nullptr, *as_ptr = nullptr, *as_x = nullptr, *as_y = nullptr;
-    T *rel = nullptr, *A = nullptr, *Dinv = nullptr, *P = nullptr, *Tv = nullptr, *Rv = nullptr;
+    using H = HT<T>;                              // hierarchy storage type (tsgo_amg_kernels.h)
+    T* rel = nullptr;
+    H *A = nullptr, *Dinv = nullptr, *P = nullptr, *Tv = nullptr, *Rv = nullptr;
     T *r = nullptr, *z = nullptr, *res = nullptr, *z2 = nullptr;
 };
 
@@ -116,7 +118,9 @@ template <typename T> struct Engine : IEngine {
     std::vector<DevLevel<T>> lv;
     int *sc_ptr = nullptr, *sc_optr = nullptr; uint32_t *sc_si = nullptr, *sc_sk = nullptr, *sc_os = nullptr;
     int *last_ptr = nullptr, *last_col = nullptr; int nb_last = 0, nnz_last = 0;
-    T *A_last = nullptr, *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr;
+    using H = HT<T>;
+    H* A_last = nullptr;
+    T *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr;
     double ms_amg_symbolic = 0;
     T *omega_dev = nullptr, *one_dev = nullptr, *pw_a = nullptr, *pw_b = nullptr, *rho_part = nullptr;
     T* h_rho = nullptr;                 // pinned
@@ -346,16 +350,16 @@ template <typename T> struct Engine : IEngine {
                            sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A);
         for (size_t l = 0; l < lv.size(); ++l) {
             DevLevel<T>& L = lv[l];
-            T* Anext = l + 1 < lv.size() ? lv[l + 1].A : A_last;
-            hipLaunchKernelGGL((k_block_inv<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.diag, (const T*)L.A, L.Dinv);
+            H* Anext = l + 1 < lv.size() ? lv[l + 1].A : A_last;
+            hipLaunchKernelGGL((k_block_inv<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.diag, (const H*)L.A, L.Dinv);
             hipLaunchKernelGGL((k_prolongator<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, L.P_row, L.p_self, L.ps_ptr, L.ps_x, L.ps_y,
-                               (const T*)L.A, (const T*)L.Dinv, (const T*)L.rel, (T)kProlongOmega, L.P, L.p_to_r, L.Rv);
-            if (L.pairs_T > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 0>), dim3(grid_for(L.nnzT, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const T*)L.A, (const T*)L.P, L.Tv);
-            else hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for((L.nnzT + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const T*)L.A, (const T*)L.P, L.Tv);
-            if (L.pairs_A > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1>), dim3(grid_for(L.nnzNext, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const T*)L.P, (const T*)L.Tv, Anext);
-            else hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.nnzNext + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const T*)L.P, (const T*)L.Tv, Anext);
+                               (const H*)L.A, (const H*)L.Dinv, (const T*)L.rel, (T)kProlongOmega, L.P, L.p_to_r, L.Rv);
+            if (L.pairs_T > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 0>), dim3(grid_for(L.nnzT, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv);
+            else hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for((L.nnzT + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv);
+            if (L.pairs_A > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1>), dim3(grid_for(L.nnzNext, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext);
+            else hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.nnzNext + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext);
         }
-        hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kDenseThreads), 0, stream, nb_last, last_ptr, last_col, (const T*)A_last, inv_last);
+        hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kDenseThreads), 0, stream, nb_last, last_ptr, last_col, (const H*)A_last, inv_last);
     }
 
     static int lanes_for(double avg_row) { return avg_row <= 4 ? 4 : (avg_row <= 12 ? 8 : (avg_row <= 40 ? 32 : 64)); }
@@ -370,10 +374,10 @@ template <typename T> struct Engine : IEngine {
     } while (0)
     void launch_prolong(DevLevel<T>& L, const T* e, T* z, int zs, const CgState<T>* s) {
         switch (lanes_for((double)L.nnzP / std::max(1, L.n))) {
-            case 4: hipLaunchKernelGGL((k_prolong_add<T, 4>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, z, zs, s); break;
-            case 8: hipLaunchKernelGGL((k_prolong_add<T, 8>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, z, zs, s); break;
-            case 32: hipLaunchKernelGGL((k_prolong_add<T, 32>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, z, zs, s); break;
-            default: hipLaunchKernelGGL((k_prolong_add<T, 64>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const T*)L.P, e, z, zs, s); break;
+            case 4: hipLaunchKernelGGL((k_prolong_add<T, 4>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.P, e, z, zs, s); break;
+            case 8: hipLaunchKernelGGL((k_prolong_add<T, 8>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.P, e, z, zs, s); break;
+            case 32: hipLaunchKernelGGL((k_prolong_add<T, 32>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.P, e, z, zs, s); break;
+            default: hipLaunchKernelGGL((k_prolong_add<T, 64>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.P, e, z, zs, s); break;
         }
     }
 
@@ -389,7 +393,7 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL((k_seed_vector<T>), dim3(grid_for(n3)), dim3(kBlock), 0, stream, n3, a);
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
             for (int it = 0; it < kRhoSteps; ++it) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 2, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)a, (const T*)a, (const T*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]);
+                LAUNCH_LPR(lprA, k_bcsr_residual, 2, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]);
                 std::swap(a, b);
             }
             // a = v_K, b = v_{K-1}
@@ -425,7 +429,7 @@ template <typename T> struct Engine : IEngine {
         {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, (const T*)r, (const T*)sbuf, lv[1].r, (const T*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
+            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv, (const T*)r, (const T*)sbuf, lv[1].r, (const H*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
         }
         // coarse levels: V(nu,nu) with nu = coarse_sweeps block-Jacobi sweeps (the first pre-sweep comes fused
         // with the restriction above).  The current iterate alternates between L.z and L.z2; it ends in L.z2.
@@ -435,13 +439,13 @@ template <typename T> struct Engine : IEngine {
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
             T* cur = L.z; T* oth = L.z2;
             for (int sw = 1; sw < nu; ++sw) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, oth, (const T*)(omega_dev + l), s);
+                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, oth, (const T*)(omega_dev + l), s);
                 std::swap(cur, oth);
             }
-            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, L.res, (const T*)(omega_dev + l), s);
+            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, L.res, (const T*)(omega_dev + l), s);
             if (l + 1 < nl) {
                 const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const T*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
+                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const H*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
             }
         }
         // iterate of level l after the down pass: L.z when nu is odd, L.z2 when even
@@ -449,12 +453,12 @@ template <typename T> struct Engine : IEngine {
         auto down_other = [&](DevLevel<T>& L) { return (nu % 2) ? L.z2 : L.z; };
         if (nl > 1) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
             DevLevel<T>& L = lv[nl - 1];
-            hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kDenseThreads), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv, L.P_ptr, L.P_col, (const T*)L.P,
+            hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kDenseThreads), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv, L.P_ptr, L.P_col, (const H*)L.P,
                                (const T*)L.res, (const T*)inv_last, down_iter(L), s);
         } else {        // only level 0 above the dense level: residual r - S z is restricted from (r, sbuf)
             DevLevel<T>& L = lv[0];
-            hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const T*)L.Rv,
-                               (const T*)r, (const T*)sbuf, r_last, (const T*)nullptr, (T*)nullptr, (const T*)one_dev, s);
+            hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv,
+                               (const T*)r, (const T*)sbuf, r_last, (const H*)nullptr, (T*)nullptr, (const T*)one_dev, s);
             hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
         }
         for (size_t l = nl - 1; l >= 1; --l) {
@@ -463,7 +467,7 @@ template <typename T> struct Engine : IEngine {
             if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, cur, 3, s);
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
             for (int sw = 0; sw < nu; ++sw) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const T*)L.A, (const T*)L.r, (const T*)cur, (const T*)L.Dinv, oth, (const T*)(omega_dev + l), s);
+                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, oth, (const T*)(omega_dev + l), s);
                 std::swap(cur, oth);
             }
             // nu post-sweeps after nu-1 pre-swaps: the result sits in L.z2 for every nu (odd+odd / even+even swaps)

@@ -60,6 +60,25 @@ using namespace tsgo;
         }                                                                                              \
     } while (0)
 
+#define LAUNCH_GML(G, KERNEL, MODE, LOW, grid, stream, ...)                                             \
+    do {                                                                                               \
+        switch (G) {                                                                                   \
+            case 1: hipLaunchKernelGGL((KERNEL<T, 1, MODE, LOW>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 2: hipLaunchKernelGGL((KERNEL<T, 2, MODE, LOW>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL((KERNEL<T, 4, MODE, LOW>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((KERNEL<T, 8, MODE, LOW>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+        }                                                                                              \
+    } while (0)
+#define LAUNCH_GML1(G, KERNEL, LOW, grid, stream, ...)                                                 \
+    do {                                                                                               \
+        switch (G) {                                                                                   \
+            case 1: hipLaunchKernelGGL((KERNEL<T, 1, LOW>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 2: hipLaunchKernelGGL((KERNEL<T, 2, LOW>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL((KERNEL<T, 4, LOW>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((KERNEL<T, 8, LOW>), dim3(grid), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+        }                                                                                              \
+    } while (0)
+
 struct IEngine {
     virtual ~IEngine() {}
     virtual int set_graph(const tsgo_graph& g) = 0;
@@ -127,9 +146,11 @@ template <typename T> struct Engine : IEngine {
     std::vector<double> omega_host;    // smoother damping per level (diagnostics)
     int lin_count = 0;
     int coarse_sweeps = kCoarseSweeps;
+    bool low_cycle = true;     // f32 slot planes for the Schur products inside the multigrid cycle
 
     explicit Engine(const tsgo_config& c) : cfg(c) {
         if (const char* e = getenv("TSGO_COARSE_SWEEPS")) coarse_sweeps = std::max(1, std::min(4, atoi(e)));
+        if (const char* e = getenv("TSGO_CYCLE_F64")) low_cycle = atoi(e) == 0;
     }
 
     ~Engine() override { release(); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
@@ -264,6 +285,8 @@ template <typename T> struct Engine : IEngine {
         if (int rc = upload_T(&stp, src, h.planes.size())) return rc;
         t.st = stp;
         if (int rc = dalloc(&t.dyn, (size_t)dyn_planes * h.slots())) return rc;
+        t.dyn32 = nullptr;
+        if (pairs) { if (int rc = dalloc(&t.dyn32, h.slots())) return rc; HIP_OK(hipMemset(t.dyn32, 0, std::max<size_t>(h.slots(), 1) * sizeof(float4))); }
         HIP_OK(hipMemset(t.dyn, 0, std::max<size_t>((size_t)dyn_planes * h.slots(), 1) * sizeof(T)));
         return 0;
     }
@@ -336,7 +359,15 @@ template <typename T> struct Engine : IEngine {
     void launch_finalize() {
         hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0], (const T*)(amg_on ? omega_dev : one_dev));
     }
-    void launch_matvec(int slot, bool with_rz = false) {   // S * (vector in zc) -> sbuf, dot partials behind it
+    // S * (vector in zc) -> sbuf, dot partials behind it.  low: read the f32 copy of the slot planes (the two
+    // products inside the multigrid cycle; never the product PCG itself takes).
+    void launch_matvec(int slot, bool with_rz = false, bool low = false) {
+        if (low) {
+            if (tl.n_slices > 0) LAUNCH_GML(pr.by_lm.G, k_schur_lm, 0, 1, nbL, stream, tl, zc, lmrec, tvec, st[slot], T(0), dl, npart);
+            LAUNCH_GML1(pr.by_pose.G, k_schur_pose, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
+                        (const T*)nullptr, rzpart);
+            return;
+        }
         if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, tvec, st[slot], T(0), dl, npart);
         LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
                  (const T*)(with_rz ? r : nullptr), rzpart);
@@ -425,7 +456,7 @@ template <typename T> struct Engine : IEngine {
     void launch_vcycle(int slot) {
         const CgState<T>* s = st[slot];
         const size_t nl = lv.size();              // explicit levels 0 .. nl-1, dense level below
-        launch_matvec(slot);
+        launch_matvec(slot, false, low_cycle);
         {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
@@ -473,7 +504,7 @@ template <typename T> struct Engine : IEngine {
             // nu post-sweeps after nu-1 pre-swaps: the result sits in L.z2 for every nu (odd+odd / even+even swaps)
         }
         launch_prolong(lv[0], nl > 1 ? (const T*)lv[1].z2 : (const T*)z_last, zc, kPoseRec, s);
-        launch_matvec(slot);
+        launch_matvec(slot, false, low_cycle);
         hipLaunchKernelGGL((k_smooth0<T, 1>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, (const T*)omega_dev, s);
     }
     void launch_cg_step(int slot) {

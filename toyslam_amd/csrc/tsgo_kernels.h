@@ -52,9 +52,11 @@ template <typename T> struct CgState { T gamma_old, alpha_old, gamma0, pad; int 
 // LM tables keep their per-slot values as 16-byte PAIRS, pair-plane-major: st = [(zx,zy) | (w0,w1)],
 // dyn = [(a0,a1) | (ppx,ppy)], element k of pair-plane q at (q*slots + k)*2: one dwordx4 per lane and
 // plane instead of two dwordx2 (8-byte lanes stream at 0.54-0.70x the 16-byte rate, MI355X_MICROARCH.md).
-// The ODOM table keeps single-value planes.
+// The ODOM table keeps single-value planes.  dyn32 = the same four numbers of every LM slot as ONE float4: the two
+// Schur products INSIDE the multigrid cycle read it instead (a preconditioner tolerates f32 operands; the
+// product PCG itself takes stays f64).
 template <typename T> struct Table {       // one SELL table on the device
-    const uint32_t* row_off; const uint32_t* idx; const T* st; T* dyn; size_t slots; int n_slices; int n_vertices; int xcd;
+    const uint32_t* row_off; const uint32_t* idx; const T* st; T* dyn; float4* dyn32; size_t slots; int n_slices; int n_vertices; int xcd;
 };
 
 // XCD-aware workgroup -> slice-group map (guide T1).  Workgroups are dealt round-robin over the 8 XCDs,
@@ -124,6 +126,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restr
         const T x = q01.x, y = q01.y, c = q23.x, s = q23.y;
         const LmLin<T> o = lm_linearize<T>(x, y, c, s, lx, ly, zx, zy, w0, w1);
         st2<T>(tb.dyn + 2 * k, o.a0, o.a1); st2<T>(tb.dyn + 2 * (S + k), o.ppx, o.ppy);
+        tb.dyn32[k] = make_float4((float)o.a0, (float)o.a1, (float)o.ppx, (float)o.ppy);
         dxx += o.a0 * c * c + o.a1 * s * s; dxy += (o.a0 - o.a1) * c * s; dyy += o.a0 * s * s + o.a1 * c * c;
         const T f0 = o.a0 * o.e0, f1 = o.a1 * o.e1;
         g0 -= c * f0 - s * f1; g1 -= s * f0 + c * f1;
@@ -174,6 +177,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
                 const T lx = l01.x, ly = l01.y, nxx = l23.x, nxy = l23.y, nyy = l45.x, ux = l45.y, uy = lr[6];
                 const LmLin<T> o = lm_linearize<T>(x0, y0, c, s, lx, ly, zx, zy, w0, w1);
                 st2<T>(tb.dyn + 2 * k, o.a0, o.a1); st2<T>(tb.dyn + 2 * (S + k), o.ppx, o.ppy);
+                tb.dyn32[k] = make_float4((float)o.a0, (float)o.a1, (float)o.ppx, (float)o.ppy);
                 chi += o.rho;
                 const T v0 = o.ppy, v1 = -o.ppx;
                 sA0 += o.a0; sA1 += o.a1; sAv0 += o.a0 * v0; sAv1 += o.a1 * v1; sVV += o.a0 * v0 * v0 + o.a1 * v1 * v1;
@@ -281,7 +285,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __rest
 // KA schur_lm: per landmark — t = Dl^-1 W^T v, v being the vector held in zc[.][0..2].
 //   MODE 0: write t.   MODE 1 (back-substitution): dl = u - t, landmark += step * dl, |dl|^2 partial.
 // HOT KERNEL 1 of the PCG iteration.
-template <typename T, int G, int MODE>
+template <typename T, int G, int MODE, int LOW = 0>
 __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __restrict__ zc, T* __restrict__ lmrec,
                                                      T* __restrict__ t, const CgState<T>* __restrict__ st,
                                                      T step, T* __restrict__ dl_out, T* __restrict__ norm_part) {
@@ -312,8 +316,11 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
                 const uint32_t row = min(base + u, r1 - 1);
                 const size_t k = (size_t)row * 64 + lane;
                 i[u] = tb.idx[k];
-                const auto aa = ld2<T>(tb.dyn + 2 * k), pp = ld2<T>(tb.dyn + 2 * (S + k));
-                a0[u] = aa.x; a1[u] = aa.y; ppx[u] = pp.x; ppy[u] = pp.y;
+                if (LOW) { const float4 f = tb.dyn32[k]; a0[u] = f.x; a1[u] = f.y; ppx[u] = f.z; ppy[u] = f.w; }
+                else {
+                    const auto aa = ld2<T>(tb.dyn + 2 * k), pp = ld2<T>(tb.dyn + 2 * (S + k));
+                    a0[u] = aa.x; a1[u] = aa.y; ppx[u] = pp.x; ppy[u] = pp.y;
+                }
             }
             T v0[UB], v1[UB], v2[UB], c[UB], s[UB];
 #pragma unroll
@@ -354,7 +361,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
 // ------------------------------------------------------------------------------------------------
 // KB schur_pose: per pose — out = Hpp v - W t (this shard's share), partial dot (out, v).
 // HOT KERNEL 2 of the PCG iteration.
-template <typename T, int G>
+template <typename T, int G, int LOW = 0>
 __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od, const T* __restrict__ zc,
                                                        const T* __restrict__ t, const T* __restrict__ dp,
                                                        int pose_first, int pose_last, T* __restrict__ out,
@@ -381,8 +388,12 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
             for (uint32_t row = r0; row < r1; ++row) {
                 const size_t k = (size_t)row * 64 + lane;
                 const uint32_t l = tb.idx[k];
-                const auto aa = ld2<T>(tb.dyn + 2 * k), pp = ld2<T>(tb.dyn + 2 * (S + k));
-                const T a0 = aa.x, a1 = aa.y, ppx = pp.x, ppy = pp.y;
+                T a0, a1, ppx, ppy;
+                if (LOW) { const float4 f = tb.dyn32[k]; a0 = f.x; a1 = f.y; ppx = f.z; ppy = f.w; }
+                else {
+                    const auto aa = ld2<T>(tb.dyn + 2 * k), pp = ld2<T>(tb.dyn + 2 * (S + k));
+                    a0 = aa.x; a1 = aa.y; ppx = pp.x; ppy = pp.y;
+                }
                 const auto txy = ld2<T>(t + (size_t)l * 2);
                 const T tx = txy.x, ty = txy.y;
                 const T t0 = a0 * (c * tx + s * ty), t1 = a1 * (c * ty - s * tx);

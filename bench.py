@@ -43,8 +43,10 @@ def pmc_traffic(kernel, workload, precision):
         d = json.load(open(PMC_TRAFFIC))
         if d.get("workload") != workload or d.get("precision") != precision:
             return None
+        # the instance tsgo_time_kernel launches: f64 slot planes (LOW = 0), product mode (MODE = 0)
+        ending = {"k_schur_lm": ", 0, 0>", "k_schur_pose": ", 0>"}.get(kernel, ">")
         for k, v in d["kernels"].items():
-            if k.startswith(kernel + "<"):
+            if k.startswith(kernel + "<") and k.endswith(ending):
                 return v["hbm_bytes_corrected"]
     except (OSError, ValueError, KeyError):
         pass

@@ -170,6 +170,14 @@ def main():
                          "us_per_pcg_iteration": opt.time_kernel(5, reps=20)[0],
                          "us_multigrid_numeric_setup": opt.time_kernel(6, reps=5)[0] if amg else None},
         }
+        if world == 1 and not ARGS.no_conv:
+            # the second half of BASELINE.json's metric: Gauss-Newton iterations until the reference's plateau rule
+            # |chi2_k - chi2_{k-1}| < 1e-3 fires (OptimizerCpu.h:167-171), capped at 50; a fresh run, outside the timed region
+            opt.set_graph(g)
+            rc = opt.optimize(50)
+            out["iters_to_chi2_tol"] = {"iterations": int(rc["iters"]), "stop": rc["stop"], "cap": 50, "chi2_first": float(rc["chi2"][0]),
+                                        "chi2_last": float(rc["chi2"][-1]), "pcg_iters_total": int(rc["cg_total"]),
+                                        "seconds": rc["ms_total"] / 1e3, "pcg_fallbacks": int(rc["fallbacks"])}
         if world == 1 and not ARGS.no_cpu:
             out["cpu_baseline"] = cpu_baseline(g, ARGS.cpu_threads or min(16, len(os.sched_getaffinity(0))))
     opt.close()
@@ -192,6 +200,7 @@ if __name__ == "__main__":
     ap.add_argument("--shard", action="store_true", help="N > 1: split ONE graph by edge set (strong scaling)")
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true")
     ap.add_argument("--no-cpu", dest="no_cpu", action="store_true")
+    ap.add_argument("--no-conv", dest="no_conv", action="store_true", help="skip the 50-iteration convergence run")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0)
     ap.add_argument("--lanes-pose", dest="lanes_pose", type=int, default=0)
     ap.add_argument("--lanes-lm", dest="lanes_lm", type=int, default=0)

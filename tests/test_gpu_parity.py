@@ -255,3 +255,33 @@ def test_vertex_and_edge_order_do_not_matter_on_the_device(opt):
     opt.set_graph(gs); b = opt.optimize(6); vb = opt.vertices()
     np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-10)
     assert util.max_vertex_diff(va[pv], vb, gs.v_type) < 1e-9
+
+
+def test_randomised_graphs_against_cpu_eigen():
+    """Differential soak: 24 random graphs (sizes, observation counts, loop closures, fixed sets, both
+    preconditioners alternating) — one exact step and three GN iterations against the dense restatement."""
+    rng = np.random.default_rng(1234)
+    worst = 0.0
+    for trial in range(24):
+        n = int(rng.integers(8, 260)); k = int(rng.integers(1, 9)); lc = int(rng.integers(0, 6))
+        g = synth.make(n, k, loop_closures=lc, seed=int(rng.integers(0, 10 ** 6)))
+        fx = [0] + [int(v) for v in rng.choice(g.v_id, size=int(rng.integers(0, 3)), replace=False)]
+        g.fixed = np.array(fx, np.uint32)
+        d_ref, err, _, _ = util.dense_solution(g)
+        ref = oracle.optimize(util.to_oracle(g), 3, mode="cpp", solver="chol")
+        o = HipOptimizer(pcg_rel_tol=1e-12, preconditioner="amg" if trial % 2 == 0 else "jacobi",
+                         lanes_per_pose=int(rng.choice([0, 1, 2, 4])), lanes_per_lm=int(rng.choice([0, 1, 2, 4, 8])))
+        try:
+            o.set_graph(g)
+            step = o.solve_step()
+            r = o.optimize(3)
+            v = o.vertices()
+        finally:
+            o.close()
+        assert abs(step["chi2"] - err) <= 1e-11 * max(err, 1.0), (trial, n, k)
+        dd = np.abs(step["delta"] - d_ref).max() / max(np.abs(d_ref).max(), 1e-12)
+        worst = max(worst, dd)
+        assert dd <= 1e-7, (trial, n, k, lc, dd)
+        np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-8)
+        assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-7, (trial, n, k)
+    assert worst <= 1e-7

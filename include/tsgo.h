@@ -62,6 +62,8 @@ typedef struct tsgo_config {
     int32_t preconditioner;  /* 1 (default, single shard): smoothed-aggregation multigrid V-cycle on the reduced
                                 pose system; 0: block-Jacobi on its 3x3 diagonal (always used when world > 1) */
     int32_t xcd_map;         /* 1: workgroup -> slice map gives each XCD a contiguous eighth of the vertices; 0: round-robin */
+    int32_t warm_start;      /* 1 (default): PCG starts from (1 - step) * the previous Gauss-Newton iteration's pose delta
+                                (the un-taken remainder of the last step); 0: from zero.  Same answer to pcg_rel_tol. */
 } tsgo_config;
 
 enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_CONVERGED = 3, TSGO_STOP_SOLVER = 4 };

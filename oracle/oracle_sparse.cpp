@@ -18,6 +18,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -321,13 +322,33 @@ struct Twin {
         return dot;
     }
 
-    // one linearisation: fills everything CG needs; returns gamma0
-    double linearize() {
+    // one linearisation: fills everything CG needs; returns gamma = r^T M^-1 r of the first residual and leaves
+    // in gamma_ref the value the stopping rule compares against.  warm (optional): pose delta of the previous
+    // Gauss-Newton iteration; PCG then starts from x0 = (1 - step) * warm, the un-taken remainder of that step
+    // (r = b~ - S x0), and gamma_ref = gamma * (b^T D^-1 b) / (r0^T D^-1 r0) keeps the rule relative to b~.
+    double gamma_ref = 0;
+    double linearize(const std::vector<double>* warm = nullptr) {
         lin_lm(); lin_pose();
         // gauge of owned poses goes into the partial so that it is summed exactly once across shards
         for (int i = pr.pose_first; i < pr.pose_last; ++i) { part[(size_t)i * 18] += pr.gauge_p[i]; part[(size_t)i * 18 + 3] += pr.gauge_p[i]; part[(size_t)i * 18 + 5] += pr.gauge_p[i]; }
         allreduce(part.data(), (int64_t)part.size());
-        const double g0 = finalize();
+        double g0 = finalize();
+        double scale = 1;
+        if (warm && warm->size() == x.size()) {
+            for (size_t k = 0; k < x.size(); ++k) x[k] = (1.0 - tsgo::kStepScale) * (*warm)[k];
+            std::vector<double> buf((size_t)P * 3 + 1);
+            schur_lm(x);
+            buf[(size_t)P * 3] = schur_pose(x, buf);
+            allreduce(buf.data(), (int64_t)buf.size());
+            double nr = 0;
+            for (int i = 0; i < P; ++i) {
+                for (int k = 0; k < 3; ++k) r[3 * (size_t)i + k] -= buf[3 * (size_t)i + k];
+                tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
+                for (int k = 0; k < 3; ++k) nr += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
+            }
+            if (nr > 0 && g0 > nr) scale = g0 / nr;
+            g0 = nr;
+        }
         if (use_amg) {
             static const int lag = getenv("TSGO_TWIN_LAG") ? atoi(getenv("TSGO_TWIN_LAG")) : 1;
             if (!amg.levels.empty() && (n_lin % lag) == 0) { build_schur_blocks(); hier.setup_from_level0(); }
@@ -335,15 +356,18 @@ struct Twin {
             amg_apply();
             double g = 0;
             for (int i = 0; i < 3 * P; ++i) g += r[i] * z[i];
+            gamma_ref = g * scale;
             return g;
         }
+        gamma_ref = g0 * scale;
         return g0;
     }
 
     // Chronopoulos-Gear PCG on the reduced (pose) system S x = b~.  Returns iterations.
-    int solve(double gamma0, double tol, int max_it, bool* ok) {
+    int solve(double gamma_first, double tol, int max_it, bool* ok) {
         std::vector<double> buf((size_t)P * 3 + 1);
-        double gamma = gamma0, gamma_old = 0, alpha_old = 0;
+        const double gamma0 = gamma_ref;
+        double gamma = gamma_first, gamma_old = 0, alpha_old = 0;
         *ok = true;
         if (!(gamma0 > 0)) return 0;
         int it = 0;
@@ -466,19 +490,22 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
     if (precond == 1 && !tw.enable_amg().empty()) return -5;
     std::memcpy(v_pos_out, v_pos, sizeof(double) * 3 * (size_t)nV);
     double prevErr = -1; int penalty = 0;
+    std::vector<double> xprev;
     *stop_reason = 0; *iters_run = 0; *last_delta_norm = 0;
     if (seconds_lin) *seconds_lin = 0;
     if (seconds_solve) *seconds_solve = 0;
     auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
     for (int it = 0; it < iterations; ++it) {
         double t0 = now();
-        const double gamma0 = tw.linearize();
+        static const bool cold = getenv("TSGO_TWIN_COLD") != nullptr;
+        const double gamma0 = tw.linearize(it > 0 && !cold ? &xprev : nullptr);
         double t1 = now(); if (seconds_lin) *seconds_lin += t1 - t0;
         const double err = tw.chi2;
         chi2_trace[it] = err; *iters_run = it + 1;
         if (prevErr > 0 && err > prevErr) { if (++penalty > 2) { *stop_reason = 1; break; } } else penalty = 0;
         bool ok; cg_trace[it] = tw.solve(gamma0, pcg_tol, max_cg, &ok);
         if (!ok) { *stop_reason = 4; break; }
+        xprev = tw.x;
         std::vector<double> dl; tw.backsub(dl);
         const double nrm = tw.update(dl);
         if (seconds_solve) *seconds_solve += now() - t1;

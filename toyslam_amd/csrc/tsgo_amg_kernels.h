@@ -428,14 +428,15 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
                                                     const T* __restrict__ rz_part, int n_part, const CgState<T>* __restrict__ st_in,
                                                     CgState<T>* __restrict__ st_out, T* __restrict__ r, T* __restrict__ p,
                                                     T* __restrict__ q, T* __restrict__ x, T* __restrict__ zc,
-                                                    const T* __restrict__ minv, const T* __restrict__ omega_ptr, T tol2, int max_iters) {
+                                                    const T* __restrict__ minv, const T* __restrict__ omega_ptr, T tol2, int max_iters,
+                                                    const T* __restrict__ gamma0_scale) {
     __shared__ T red[kWavesPerBlock];
     const CgState<T> s = *st_in;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
     if (s.done) { if (writer) *st_out = s; return; }
     const T delta = block_sum_array<T>(dot_part, n_part, red);
     const T gamma = block_sum_array<T>(rz_part, n_part, red);
-    const T gamma0 = s.iters == 0 ? gamma : s.gamma0;
+    const T gamma0 = s.iters == 0 ? gamma * (*gamma0_scale) : s.gamma0;
     CgState<T> n = s; n.gamma0 = gamma0;
     if (!(gamma > tol2 * gamma0) || s.iters >= max_iters) {
         // gamma = r^T M^-1 r < 0 (or NaN) means the preconditioner is not positive definite: breakdown,

@@ -141,10 +141,11 @@ template <typename T> struct Engine : IEngine {
     H* A_last = nullptr;
     T *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr;
     double ms_amg_symbolic = 0;
-    T *omega_dev = nullptr, *one_dev = nullptr, *pw_a = nullptr, *pw_b = nullptr, *rho_part = nullptr;
+    T *omega_dev = nullptr, *one_dev = nullptr, *gscale_dev = nullptr, *xprev = nullptr, *pw_a = nullptr, *pw_b = nullptr, *rho_part = nullptr;
     T* h_rho = nullptr;                 // pinned
     std::vector<double> omega_host;    // smoother damping per level (diagnostics)
     int lin_count = 0;
+    bool have_prev = false;            // xprev holds the pose delta of the previous solve (warm start)
     int coarse_sweeps = kCoarseSweeps;
     bool low_cycle = true;     // f32 slot planes for the Schur products inside the multigrid cycle
 
@@ -337,7 +338,10 @@ template <typename T> struct Engine : IEngine {
         for (int k = 0; k < 2; ++k) { if (int rc = dalloc(&gpart[k], nbC)) return rc; if (int rc = dalloc(&st[k], 1)) return rc; }
         if (int rc = dalloc(&npart, (size_t)nbC + std::max(nbL, 1))) return rc;
         if (int rc = dalloc(&one_dev, 1)) return rc;
-        { const T one = 1; HIP_OK(hipMemcpy(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)); }
+        if (int rc = dalloc(&gscale_dev, 1)) return rc;
+        if (int rc = dalloc(&xprev, (size_t)P * 3)) return rc;
+        have_prev = false;
+        { const T one = 1; HIP_OK(hipMemcpy(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)); }
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
         HIP_OK(hipDeviceSynchronize());
@@ -357,7 +361,7 @@ template <typename T> struct Engine : IEngine {
         LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18);
     }
     void launch_finalize() {
-        hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0], (const T*)(amg_on ? omega_dev : one_dev));
+        hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0], (const T*)(amg_on ? omega_dev : one_dev), gscale_dev);
     }
     // S * (vector in zc) -> sbuf, dot partials behind it.  low: read the f32 copy of the slot planes (the two
     // products inside the multigrid cycle; never the product PCG itself takes).
@@ -510,7 +514,7 @@ template <typename T> struct Engine : IEngine {
     void launch_cg_step(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
         hipLaunchKernelGGL((k_cg_step<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)(sbuf + (size_t)pr.P * 3), (const T*)rzpart, nbP,
-                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, (const T*)omega_dev, tol2, std::min(cfg.pcg_max_iters, kAmgIterCap));
+                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, (const T*)omega_dev, tol2, std::min(cfg.pcg_max_iters, kAmgIterCap), (const T*)gscale_dev);
     }
     // one PCG iteration reading state slot `slot`, writing slot^1
     void launch_iteration(int slot) {
@@ -521,7 +525,7 @@ template <typename T> struct Engine : IEngine {
     void launch_cg_update(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
         hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[slot], nbC,
-                           gpart[slot ^ 1], st[slot], st[slot ^ 1], minv, r, p, q, x, zc, tol2, cfg.pcg_max_iters);
+                           gpart[slot ^ 1], st[slot], st[slot ^ 1], minv, r, p, q, x, zc, tol2, cfg.pcg_max_iters, (const T*)gscale_dev);
     }
     int allreduce(T* buf, size_t n) {
         if (pr.world <= 1) return 0;
@@ -562,7 +566,19 @@ template <typename T> struct Engine : IEngine {
     // PCG; if the multigrid-preconditioned solve breaks down (indefinite preconditioner), the solve is
     // repeated from the same right-hand side with the block-Jacobi preconditioner.
     int n_fallbacks = 0;
+    // Warm start (cfg.warm_start): the Gauss-Newton update takes kStepScale of the solved delta, so (1 - kStepScale) of it
+    // is still to go at the next linearisation.  x0 = that remainder, r = b~ - S x0 (one extra product), and the stopping
+    // rule keeps measuring against the right-hand side: gamma0 is scaled by (b^T D^-1 b) / (r0^T D^-1 r0).
+    int launch_warm() {
+        hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, (T)(1.0 - kStepScale));
+        launch_matvec(0);
+        if (int rc = allreduce(sbuf, (size_t)pr.P * 3 + nbP)) return rc;
+        hipLaunchKernelGGL((k_warm_residual<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)minv, r, zc, (const T*)(amg_on ? omega_dev : one_dev), npart);
+        hipLaunchKernelGGL((k_warm_scale<T>), dim3(1), dim3(kBlock), 0, stream, nbC, (const T*)gpart[0], (const T*)npart, amg_on ? (T*)nullptr : gpart[0], gscale_dev);
+        return 0;
+    }
     int do_solve(int* iters, int* fail) {
+        if (cfg.warm_start && have_prev) { if (int rc = launch_warm()) return rc; }
         if (int rc = do_solve_once(iters, fail)) return rc;
         if (*fail == 0 && amg_on) {
             // certify the multigrid-preconditioned solve in a norm the multigrid operator has no part in:
@@ -620,7 +636,8 @@ template <typename T> struct Engine : IEngine {
     // landmarks: dl = u - Dl^-1 W^T x (+ optional update); poses: update; returns ||delta||
     int do_backsub_update(T step, double* delta_norm) {
         const int P = pr.P;
-        hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, zc);
+        hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, zc, xprev, (const T*)nullptr, T(0));
+        have_prev = step != T(0);     // a probe (step 0) leaves nothing to carry over
         if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 1, nbL, stream, tl, zc, lmrec, tvec, st[0], step, dl, npart + nbC);
         hipLaunchKernelGGL((k_pose_update<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, ps, theta, step, npart);
         const int nl = tl.n_slices > 0 ? nbL : 0;
@@ -776,7 +793,7 @@ template <typename T> struct Engine : IEngine {
                     case 2: {   // state slot 1 is never written here, slot 0 stays "iters = 0, not done"
                         const T tol2 = (T)0;
                         hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[0], nbC,
-                                           gpart[1], st[0], st[1], minv, r, p, q, x, zc, tol2, 1 << 30);
+                                           gpart[1], st[0], st[1], minv, r, p, q, x, zc, tol2, 1 << 30, (const T*)one_dev);
                         break;
                     }
                     case 3: if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l); break;

@@ -250,7 +250,8 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __rest
                                                           T* __restrict__ dp, T* __restrict__ minv, T* __restrict__ r,
                                                           T* __restrict__ p, T* __restrict__ q, T* __restrict__ x,
                                                           T* __restrict__ zc, T* __restrict__ gpart,
-                                                          CgState<T>* __restrict__ st0, const T* __restrict__ omega_ptr) {
+                                                          CgState<T>* __restrict__ st0, const T* __restrict__ omega_ptr,
+                                                          T* __restrict__ gamma0_scale) {
     __shared__ T red[kWavesPerBlock];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     T g = 0;
@@ -278,6 +279,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __rest
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         CgState<T> s; s.gamma_old = 0; s.alpha_old = 0; s.gamma0 = 0; s.pad = 0; s.iters = 0; s.done = 0; s.fail = 0; s.pad2 = 0;
         *st0 = s;
+        *gamma0_scale = 1;       // cold start; the warm-start kernels overwrite it
     }
 }
 
@@ -445,14 +447,16 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int P, const T* __restrict
                                                       T* __restrict__ gpart_out, const CgState<T>* __restrict__ st_in,
                                                       CgState<T>* __restrict__ st_out, const T* __restrict__ minv,
                                                       T* __restrict__ r, T* __restrict__ p, T* __restrict__ q,
-                                                      T* __restrict__ x, T* __restrict__ zc, T tol2, int max_iters) {
+                                                      T* __restrict__ x, T* __restrict__ zc, T tol2, int max_iters,
+                                                      const T* __restrict__ gamma0_scale) {
     __shared__ T red[kWavesPerBlock];
     const CgState<T> s = *st_in;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
     if (s.done) { if (writer) *st_out = s; return; }
     const T delta = block_sum_array<T>(dot_part, n_dot, red);
     const T gamma = block_sum_array<T>(gpart_in, n_g, red);
-    const T gamma0 = s.iters == 0 ? gamma : s.gamma0;
+    // warm-started solves measure convergence against the right-hand side, not against the (already small) first residual
+    const T gamma0 = s.iters == 0 ? gamma * (*gamma0_scale) : s.gamma0;
     CgState<T> n = s; n.gamma0 = gamma0;
     if (!(gamma > tol2 * gamma0) || s.iters >= max_iters) {      // converged (or cap, or NaN): x is final
         n.done = 1; n.fail = (gamma != gamma) ? 1 : ((gamma > tol2 * gamma0) ? 2 : 0);
@@ -494,10 +498,51 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int P, const T* __restrict
 }
 
 // x -> zc[.][0..2] (the landmark pass reads its vector from zc)
+// scale = 0: plain copy of x into zc (and into xsave when given).  scale != 0: x = scale * xprev first (warm start).
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_pack_x(int P, const T* __restrict__ x, T* __restrict__ zc) {
+__global__ __launch_bounds__(kBlock) void k_pack_x(int P, T* __restrict__ x, T* __restrict__ zc, T* __restrict__ xsave,
+                                                   const T* __restrict__ xprev, T scale) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
-    if (i < P) { zc[(size_t)i * kPoseRec] = x[(size_t)i * 3]; zc[(size_t)i * kPoseRec + 1] = x[(size_t)i * 3 + 1]; zc[(size_t)i * kPoseRec + 2] = x[(size_t)i * 3 + 2]; }
+    if (i >= P) return;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        T v = x[(size_t)i * 3 + k];
+        if (scale != T(0)) { v = scale * xprev[(size_t)i * 3 + k]; x[(size_t)i * 3 + k] = v; }
+        zc[(size_t)i * kPoseRec + k] = v;
+        if (xsave) xsave[(size_t)i * 3 + k] = v;
+    }
+}
+
+// Warm start, second half: r = b~ - S x0 (S x0 in sx), zc = omega Minv r, partials of r^T Minv r.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_warm_residual(int P, const T* __restrict__ sx, const T* __restrict__ minv, T* __restrict__ r,
+                                                          T* __restrict__ zc, const T* __restrict__ omega_ptr, T* __restrict__ part) {
+    __shared__ T red[kWavesPerBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    T g = 0;
+    if (i < P) {
+        const T r0 = r[(size_t)i * 3] - sx[(size_t)i * 3], r1 = r[(size_t)i * 3 + 1] - sx[(size_t)i * 3 + 1], r2 = r[(size_t)i * 3 + 2] - sx[(size_t)i * 3 + 2];
+        r[(size_t)i * 3] = r0; r[(size_t)i * 3 + 1] = r1; r[(size_t)i * 3 + 2] = r2;
+        T z0, z1, z2;
+        sym3_mul<T>(minv + (size_t)i * 6, r0, r1, r2, z0, z1, z2);
+        const T w = *omega_ptr;
+        T* zr = zc + (size_t)i * kPoseRec;
+        zr[0] = w * z0; zr[1] = w * z1; zr[2] = w * z2;
+        g = r0 * z0 + r1 * z1 + r2 * z2;
+    }
+    const T total = block_sum<T>(g, red);
+    if (threadIdx.x == 0) part[blockIdx.x] = total;
+}
+
+// scale = max(1, (b^T D^-1 b) / (r0^T D^-1 r0)) from the two partial arrays; one workgroup.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_warm_scale(int n, const T* b_part, const T* __restrict__ r_part, T* gpart_out, T* __restrict__ scale) {
+    __shared__ T red[kWavesPerBlock];
+    const T nb = block_sum_array<T>(b_part, n, red);
+    const T nr = block_sum_array<T>(r_part, n, red);
+    // block-Jacobi PCG reads gamma = r^T Minv r from gpart: hand it the warm-started value
+    if (gpart_out) for (int k = threadIdx.x; k < n; k += kBlock) gpart_out[k] = r_part[k];
+    if (threadIdx.x == 0) *scale = (nr > T(0) && nb > nr) ? nb / nr : T(1);
 }
 
 // pose (+)= step * delta: VertexSe2::Update (remote/graph/vertex/VertexSe2.h:16-27) with the 0.2 of

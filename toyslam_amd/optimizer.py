@@ -16,7 +16,7 @@ STOP = {0: "cap", 1: "worse", 2: "plateau", 3: "converged", 4: "solver_failed"}
 
 class HipOptimizer:
     def __init__(self, device=0, precision=64, pcg_rel_tol=1e-10, pcg_max_iters=20000, lanes_per_pose=0,
-                 lanes_per_lm=0, use_graphs=True, rank=0, world=1, preconditioner="amg", xcd_map=None):
+                 lanes_per_lm=0, use_graphs=True, rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None):
         self.lib = _lib.hip_lib()
         cfg = _lib.tsgo_config()
         self.lib.tsgo_default_config(C.byref(cfg))
@@ -26,6 +26,8 @@ class HipOptimizer:
         cfg.preconditioner = {"jacobi": 0, "amg": 1}[preconditioner] if world == 1 else 0
         if xcd_map is not None:
             cfg.xcd_map = int(xcd_map)
+        if warm_start is not None:
+            cfg.warm_start = int(warm_start)
         self.cfg = cfg
         self.h = C.c_void_p()
         _lib.check(self.lib, self.lib.tsgo_create(C.byref(cfg), C.byref(self.h)), "tsgo_create")

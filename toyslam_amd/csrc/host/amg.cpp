@@ -7,7 +7,10 @@
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <climits>
+#include <cstdint>
 #include <numeric>
+#include <string>
 #include <thread>
 
 namespace tsgo {
@@ -175,6 +178,112 @@ void coarsen(AmgLevel& L, const std::vector<double>& xy, BlockCsr& A_next, std::
     sw2.lap("  A' = R T");
 }
 
+
+// ---- aggregation by heavy-edge matching ------------------------------------------------------------------
+// Weighted graph of the couplings (no diagonal).  Level 0: weight = number of landmarks two poses share
+// (+ their odometry edges); below: the sums over the merged groups.
+struct WGraph {
+    int n = 0;
+    std::vector<int> ptr, col;
+    std::vector<float> w;
+};
+
+// Groups of `g` (cmap: node -> group, nc groups) become the nodes of the returned graph.
+WGraph contract(const WGraph& g, const std::vector<int>& cmap, int nc) {
+    std::vector<int> mptr(nc + 1, 0), mem(g.n);
+    for (int i = 0; i < g.n; ++i) ++mptr[cmap[i] + 1];
+    for (int a = 0; a < nc; ++a) mptr[a + 1] += mptr[a];
+    { std::vector<int> cur(mptr.begin(), mptr.end() - 1); for (int i = 0; i < g.n; ++i) mem[cur[cmap[i]]++] = i; }
+    WGraph c; c.n = nc; c.ptr.assign(1, 0);
+    std::vector<int> mark(nc, -1), pos(nc, 0);
+    for (int a = 0; a < nc; ++a) {
+        for (int m = mptr[a]; m < mptr[a + 1]; ++m) {
+            const int i = mem[m];
+            for (int e = g.ptr[i]; e < g.ptr[i + 1]; ++e) {
+                const int b = cmap[g.col[e]];
+                if (b == a) continue;
+                if (mark[b] != a) { mark[b] = a; pos[b] = (int)c.col.size(); c.col.push_back(b); c.w.push_back(g.w[e]); }
+                else c.w[pos[b]] += g.w[e];
+            }
+        }
+        c.ptr.push_back((int)c.col.size());
+    }
+    return c;
+}
+
+// Aggregates of up to `target` nodes (a power of two) by log2(target) passes of heavy-edge matching: every
+// pass visits the groups in `key` order and merges each unmatched group with the unmatched neighbour it is
+// most strongly coupled to.  Groups left small at the end join their strongest neighbour.  The groups are
+// numbered by their smallest key (memory locality along the trajectory).  g is replaced by the coarse graph.
+int aggregate_by_matching(WGraph& g, std::vector<int>& key, int target, std::vector<int>& agg) {
+    const int n0 = g.n;
+    agg.resize(n0);
+    std::iota(agg.begin(), agg.end(), 0);
+    std::vector<int> size(n0, 1);
+    for (int span = 2; span <= target; span *= 2) {
+        const int n = g.n;
+        std::vector<int> visit(n);
+        std::iota(visit.begin(), visit.end(), 0);
+        std::sort(visit.begin(), visit.end(), [&](int a, int b) { return key[a] < key[b]; });
+        std::vector<int> mate(n, -1), cmap(n, -1);
+        int nc = 0;
+        for (int i : visit) {
+            if (cmap[i] >= 0) continue;
+            int best = -1; float bw = 0;
+            for (int e = g.ptr[i]; e < g.ptr[i + 1]; ++e) {
+                const int k = g.col[e];
+                if (cmap[k] >= 0 || size[i] + size[k] > span) continue;
+                if (g.w[e] > bw || (g.w[e] == bw && best >= 0 && key[k] < key[best])) { bw = g.w[e]; best = k; }
+            }
+            cmap[i] = nc;
+            if (best >= 0) cmap[best] = nc;
+            ++nc;
+        }
+        std::vector<int> nsize(nc, 0), nkey(nc, INT32_MAX);
+        for (int i = 0; i < n; ++i) { nsize[cmap[i]] += size[i]; nkey[cmap[i]] = std::min(nkey[cmap[i]], key[i]); }
+        for (int v = 0; v < n0; ++v) agg[v] = cmap[agg[v]];
+        g = contract(g, cmap, nc);
+        size.swap(nsize); key.swap(nkey);
+    }
+    // groups below a quarter of the target join the neighbour they are most strongly coupled to
+    {
+        const int n = g.n;
+        std::vector<int> cmap(n);
+        std::iota(cmap.begin(), cmap.end(), 0);
+        bool any = false;
+        for (int i = 0; i < n; ++i) {
+            if (size[i] * 4 > target) continue;
+            int best = -1; float bw = 0;
+            for (int e = g.ptr[i]; e < g.ptr[i + 1]; ++e) { const int k = g.col[e]; if (size[k] * 4 > target && g.w[e] > bw) { bw = g.w[e]; best = k; } }
+            if (best >= 0) { cmap[i] = best; any = true; }
+        }
+        if (any) {
+            std::vector<int> dense(n, -1); int nc = 0;
+            for (int i = 0; i < n; ++i) if (cmap[i] == i) dense[i] = nc++;
+            for (int i = 0; i < n; ++i) cmap[i] = dense[cmap[i]];
+            std::vector<int> nsize(nc, 0), nkey(nc, INT32_MAX);
+            for (int i = 0; i < n; ++i) { nsize[cmap[i]] += size[i]; nkey[cmap[i]] = std::min(nkey[cmap[i]], key[i]); }
+            for (int v = 0; v < n0; ++v) agg[v] = cmap[agg[v]];
+            g = contract(g, cmap, nc);
+            size.swap(nsize); key.swap(nkey);
+        }
+    }
+    // number the groups by key
+    {
+        const int n = g.n;
+        std::vector<int> ord(n), rank(n);
+        std::iota(ord.begin(), ord.end(), 0);
+        std::sort(ord.begin(), ord.end(), [&](int a, int b) { return key[a] < key[b]; });
+        for (int r = 0; r < n; ++r) rank[ord[r]] = r;
+        for (int v = 0; v < n0; ++v) agg[v] = rank[agg[v]];
+        g = contract(g, rank, n);
+        std::vector<int> nkey(n);
+        for (int i = 0; i < n; ++i) nkey[rank[i]] = key[i];
+        key.swap(nkey);
+    }
+    return g.n;
+}
+
 }  // namespace
 
 std::string build_amg(const Problem& pr, AmgSym& out) {
@@ -288,8 +397,27 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     auto agg_at = [&](size_t l) { return agg_list[std::min(l, agg_list.size() - 1)]; };
     const int agg0 = agg_at(0);
     const int smooth_levels = getenv("TSGO_SMOOTH_LEVELS") ? atoi(getenv("TSGO_SMOOTH_LEVELS")) : kSmoothLevels;
-    for (int i = 0; i < P; ++i) L0.agg[i] = S.order[i] / agg0;
-    L0.n_agg = (P + agg0 - 1) / agg0;
+    // research override: TSGO_AGG_MODE=traj cuts the trajectory into runs of consecutive poses instead (the first version)
+    const bool matching = !(getenv("TSGO_AGG_MODE") && std::string(getenv("TSGO_AGG_MODE")) == "traj");
+    WGraph wg; std::vector<int> wkey;
+    if (matching) {
+        const float w_od = getenv("TSGO_AGG_WOD") ? (float)atof(getenv("TSGO_AGG_WOD")) : kAggOdomWeight;
+        wg.n = P; wg.ptr.assign(1, 0);
+        for (int i = 0; i < P; ++i) {
+            for (int a = L0.A.ptr[i]; a < L0.A.ptr[i + 1]; ++a) {
+                if (L0.A.col[a] == i) continue;
+                const float w = (float)(S.schur.ptr[a + 1] - S.schur.ptr[a]) + w_od * (float)(S.schur.od_ptr[a + 1] - S.schur.od_ptr[a]);
+                wg.col.push_back(L0.A.col[a]); wg.w.push_back(w);
+            }
+            wg.ptr.push_back((int)wg.col.size());
+        }
+        wkey = S.order;
+        L0.n_agg = aggregate_by_matching(wg, wkey, agg0, L0.agg);
+    } else {
+        for (int i = 0; i < P; ++i) L0.agg[i] = S.order[i] / agg0;
+        L0.n_agg = (P + agg0 - 1) / agg0;
+    }
+    sw.lap("aggregation");
     AmgLevel cur = std::move(L0);
     for (;;) {
         if (cur.n <= kCoarsestMax) { S.A_last = cur.A; S.diag_last = find_diag(cur.A); break; }
@@ -302,8 +430,11 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
         cur.n = na; cur.A = std::move(A_next);
         cur.agg.resize(na);
         const int aggc = agg_at(S.levels.size());
-        for (int a = 0; a < na; ++a) cur.agg[a] = a / aggc;     // aggregates are numbered along the trajectory
-        cur.n_agg = (na + aggc - 1) / aggc;
+        if (matching && na > kCoarsestMax) cur.n_agg = aggregate_by_matching(wg, wkey, aggc, cur.agg);
+        else {
+            for (int a = 0; a < na; ++a) cur.agg[a] = a / aggc;     // aggregates are numbered along the trajectory
+            cur.n_agg = (na + aggc - 1) / aggc;
+        }
         xy = std::move(xy_next);
     }
     out = std::move(S);

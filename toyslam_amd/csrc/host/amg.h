@@ -3,10 +3,12 @@
 //
 // Why: the reference solves H delta = b with a dense QR (remote/solver/SolverEigen.h:20).  The sparse
 // replacement is PCG on S = Hpp - W Dl^-1 W^T; with a block-Jacobi preconditioner a 100k-pose graph
-// needs ~6 000 iterations per Gauss-Newton step (profiles/r01a_*).  Pose graphs are long chains with
-// sparse loop closures: their slow modes are rigid motions of trajectory pieces.  A V(1,1) cycle over
-// aggregates of 8 consecutive poses whose coarse spaces are the three rigid modes (tx, ty, rotation
-// about the aggregate's centroid), with a Jacobi-smoothed prolongator, brings that to ~50.
+// needs ~6 000 iterations per Gauss-Newton step (profiles/r01a_*).  The slow modes of a landmark-SLAM
+// pose system are rigid motions of groups of poses that see the same landmarks (consecutive poses, and
+// revisits of the same place).  Aggregates are grown by heavy-edge matching on the co-observation graph
+// (weight = shared landmarks + kAggOdomWeight per odometry edge; 4, 4, 8, 8 ... nodes per aggregate); the
+// coarse space of an aggregate is its three rigid modes (tx, ty, rotation about its centroid), the
+// prolongator is Jacobi-smoothed.  A V-cycle over that hierarchy brings PCG to ~17 iterations.
 //
 // Level l holds A_l (block CSR, 3x3 blocks; level 0 = explicit Schur complement), aggregates, the
 // prolongator P_l = (I - w D^-1 A_l) Z_l and the Galerkin product A_{l+1} = P_l^T (A_l P_l).  Every
@@ -20,8 +22,9 @@
 
 namespace tsgo {
 
-constexpr int kAggSize = 8;          // poses per aggregate on level 0
-constexpr int kAggSizesBelow[] = {4, 4, 8};   // nodes per aggregate on levels 1, 2, 3+ (the last repeats)
+constexpr int kAggSize = 4;          // poses per aggregate on level 0
+constexpr int kAggSizesBelow[] = {4, 8};      // nodes per aggregate on levels 1, 2+ (the last repeats); powers of two
+constexpr float kAggOdomWeight = 16.f;        // coupling weight of an odometry edge, in shared landmarks (see aggregate_by_matching)
 constexpr int kSmoothLevels = 99;    // levels whose prolongator is Jacobi-smoothed (the rest use the tentative one)
 constexpr int kCoarsestMax = 28;     // stop coarsening at <= this many block rows (dense inverse in LDS, <= 84 x 84)
 constexpr int kMaxPairDegree = 64;    // landmarks observed from more poses than this do not add off-diagonal level-0 blocks
@@ -71,7 +74,7 @@ struct AmgSym {
     BlockCsr A_last;                 // pattern of the coarsest matrix
     std::vector<int> diag_last;
     SchurLists schur;
-    std::vector<int> order;          // internal pose -> position along the trajectory used for aggregation
+    std::vector<int> order;          // internal pose -> position along the trajectory (visiting order and numbering of the aggregates)
 };
 
 // Builds the hierarchy for a single-shard problem.  Returns "" or an error text.

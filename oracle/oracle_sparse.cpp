@@ -48,6 +48,7 @@ struct Twin {
     std::vector<double> gscratch;
     bool use_amg = false;
     int n_lin = 0;
+    int hier_age = -1, iters_fresh = 0, iters_last = 0;   // hierarchy refresh policy, as Engine::do_linearize (tsgo_hip.hip)
     tsgo::AmgSym amg;
     amgtwin::Hierarchy hier;
     std::vector<double> res0, s0;
@@ -350,8 +351,11 @@ struct Twin {
             g0 = nr;
         }
         if (use_amg) {
-            static const int lag = getenv("TSGO_TWIN_LAG") ? atoi(getenv("TSGO_TWIN_LAG")) : 1;
-            if (!amg.levels.empty() && (n_lin % lag) == 0) { build_schur_blocks(); hier.setup_from_level0(); }
+            // the coarse matrices may lag the linearisation (level 0 never does): rebuilt after kHierMaxAge solves or
+            // when the last solve took kHierSlack iterations more than the first one on this hierarchy
+            static const int max_age = getenv("TSGO_HIER_MAX_AGE") ? std::max(1, atoi(getenv("TSGO_HIER_MAX_AGE"))) : 4;
+            const bool refresh = hier_age < 0 || hier_age >= max_age || iters_last > iters_fresh + 2;
+            if (!amg.levels.empty() && refresh) { build_schur_blocks(); hier.setup_from_level0(); hier_age = 0; }
             ++n_lin;
             amg_apply();
             double g = 0;
@@ -401,6 +405,7 @@ struct Twin {
             for (int i = 0; i < P; ++i) gnew += gi[i];       // serial: identical on every shard
             gamma_old = gamma; alpha_old = alpha; gamma = gnew;
         }
+        if (use_amg) { iters_last = it; if (hier_age == 0) iters_fresh = it; if (hier_age >= 0) ++hier_age; if (!*ok) hier_age = -1; }
         return it;
     }
 

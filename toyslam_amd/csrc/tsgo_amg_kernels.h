@@ -163,10 +163,25 @@ __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __re
     const int o = wave * 7 + lane / 9, e = lane % 9, i = e / 3, j = e % 3;
     if (o >= n_out) return;
     T acc = 0;
-    for (int q = ptr[o]; q < ptr[o + 1]; ++q) {
-        const HT<T>* a = X + (size_t)px[q] * 9; const HT<T>* b = Y + (size_t)py[q] * 9;
-        if (TRANS) acc += T(a[i]) * T(b[j]) + T(a[3 + i]) * T(b[3 + j]) + T(a[6 + i]) * T(b[6 + j]);
-        else acc += T(a[3 * i]) * T(b[j]) + T(a[3 * i + 1]) * T(b[3 + j]) + T(a[3 * i + 2]) * T(b[6 + j]);
+    // the list is walked four pairs at a time with every index load, then every value load, issued before the
+    // arithmetic: a lane's time is its chain of dependent loads (index -> block), not bandwidth
+    constexpr int U = 4;
+    const int qe = ptr[o + 1];
+    for (int q = ptr[o]; q < qe; q += U) {
+        int xi[U], yi[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int qq = q + u < qe ? q + u : qe - 1; xi[u] = px[qq]; yi[u] = py[qq]; }
+        HT<T> a[U][3], b[U][3];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const HT<T>* pa = X + (size_t)xi[u] * 9; const HT<T>* pb = Y + (size_t)yi[u] * 9;
+            if (TRANS) { a[u][0] = pa[i]; a[u][1] = pa[3 + i]; a[u][2] = pa[6 + i]; }
+            else { a[u][0] = pa[3 * i]; a[u][1] = pa[3 * i + 1]; a[u][2] = pa[3 * i + 2]; }
+            b[u][0] = pb[j]; b[u][1] = pb[3 + j]; b[u][2] = pb[6 + j];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            if (q + u < qe) acc += T(a[u][0]) * T(b[u][0]) + T(a[u][1]) * T(b[u][1]) + T(a[u][2]) * T(b[u][2]);
     }
     out[(size_t)o * 9 + e] = acc;
 }

@@ -95,6 +95,8 @@ constexpr int kAmgIterCap = 400;        // a multigrid-preconditioned solve that
                                         // failed preconditioner (stagnation) and repeated with block-Jacobi
 constexpr double kLongPairList = 24;    // Galerkin products with longer average lists use one wavefront per output block
 constexpr double kCertifySlack = 1e4;   // certificate: sqrt(r^T D^-1 r / b^T D^-1 b) <= slack * tol (norms differ by up to ~sqrt(cond))
+constexpr int kHierMaxAge = 4;          // a multigrid hierarchy serves at most this many consecutive linearisations ...
+constexpr int kHierSlack = 2;           // ... and is rebuilt as soon as a solve needs more than this many iterations over its first
 constexpr int kChunk = 16;   // PCG iterations per captured hipGraph (even: the state ring has 2 slots)
 constexpr int kChunkAmg = 2; // with the multigrid V-cycle an iteration is ~30 launches and a solve ~50 iterations
 
@@ -145,6 +147,7 @@ template <typename T> struct Engine : IEngine {
     T* h_rho = nullptr;                 // pinned
     std::vector<double> omega_host;    // smoother damping per level (diagnostics)
     int lin_count = 0;
+    int hier_age = -1, hier_max_age = kHierMaxAge, hier_slack = kHierSlack, iters_fresh = 0, iters_last = 0;   // -1: no valid hierarchy
     bool have_prev = false;            // xprev holds the pose delta of the previous solve (warm start)
     int coarse_sweeps = kCoarseSweeps;
     bool low_cycle = true;     // f32 slot planes for the Schur products inside the multigrid cycle
@@ -152,6 +155,8 @@ template <typename T> struct Engine : IEngine {
     explicit Engine(const tsgo_config& c) : cfg(c) {
         if (const char* e = getenv("TSGO_COARSE_SWEEPS")) coarse_sweeps = std::max(1, std::min(4, atoi(e)));
         if (const char* e = getenv("TSGO_CYCLE_F64")) low_cycle = atoi(e) == 0;
+        if (const char* e = getenv("TSGO_HIER_MAX_AGE")) hier_max_age = std::max(1, atoi(e));
+        if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
 
     ~Engine() override { release(); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
@@ -265,7 +270,7 @@ template <typename T> struct Engine : IEngine {
         }
         if (h_rho) (void)hipHostFree(h_rho);
         HIP_OK(hipHostMalloc((void**)&h_rho, sizeof(T) * 16 * 2 * kRhoBlocks));
-        lin_count = 0;
+        lin_count = 0; hier_age = -1;
         return 0;
     }
 
@@ -549,10 +554,17 @@ template <typename T> struct Engine : IEngine {
         if (int rc = allreduce(part, (size_t)pr.P * 18 + nbP)) return rc;
         launch_finalize();
         if (amg_on) {
-            launch_amg_setup();
-            if (lin_count++ % kRhoEvery == 0) {
-                if (int rc = estimate_damping()) return rc;
-                launch_finalize();        // zc = omega_0 Minv r with the fresh omega_0
+            // The Galerkin hierarchy is a preconditioner, not the operator: level 0 (the Schur products, its diagonal
+            // inverse) is always the current linearisation, the coarse matrices may lag.  They are rebuilt when they
+            // have served hier_max_age solves or the last solve took kHierSlack iterations more than the first one did.
+            const bool refresh = hier_age < 0 || hier_age >= hier_max_age || iters_last > iters_fresh + hier_slack;
+            if (refresh) {
+                launch_amg_setup();
+                hier_age = 0;
+                if (lin_count++ % kRhoEvery == 0) {
+                    if (int rc = estimate_damping()) return rc;
+                    launch_finalize();        // zc = omega_0 Minv r with the fresh omega_0
+                }
             }
         }
         HIP_OK(hipMemcpyAsync(h_scratch, part + (size_t)pr.P * 18, sizeof(T) * nbP, hipMemcpyDeviceToHost, stream));
@@ -595,8 +607,10 @@ template <typename T> struct Engine : IEngine {
             if (!(num <= lim * lim * den)) *fail = 1;
         }
         if (*fail == 2 && amg_on && *iters >= std::min(cfg.pcg_max_iters, kAmgIterCap) && cfg.pcg_max_iters > kAmgIterCap) *fail = 1;
+        if (amg_on) { iters_last = *iters; if (hier_age == 0) iters_fresh = *iters; if (hier_age >= 0) ++hier_age; }
         if (*fail == 1 && amg_on) {
             ++n_fallbacks;
+            hier_age = -1;                               // whatever went wrong, start from a fresh hierarchy next time
             const bool keep = amg_on; hipGraphExec_t g = cg_graph;
             amg_on = false; cg_graph = nullptr;          // eager block-Jacobi launches
             launch_finalize();

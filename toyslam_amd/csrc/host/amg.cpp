@@ -44,7 +44,7 @@ int host_threads() {
     int n = 0;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
     if (n <= 0) n = (int)std::thread::hardware_concurrency();
-    return std::max(1, std::min(8, n / 2));      // half the logical CPUs: page-fault and allocator locks stop scaling past that
+    return std::max(1, std::min(16, n / 2));     // half the logical CPUs, at most 16 (one GPU's share of an 8-GPU host)
 }
 
 // f(chunk, begin, end) over [0, n) split into contiguous chunks, one std::thread each.

@@ -304,6 +304,13 @@ template <typename T> struct Engine : IEngine {
         BuildOptions bo; bo.rank = cfg.rank; bo.world = cfg.world; bo.lanes_per_pose = cfg.lanes_per_pose; bo.lanes_per_lm = cfg.lanes_per_lm;
         const std::string err = build_problem(g, bo, pr);
         if (!err.empty()) return set_error(-2, "tsgo_set_graph: " + err);
+        const bool say = cfg.verbose || getenv("TSGO_VERBOSE");
+        auto lap = [&, last = t0](const char* what) mutable {
+            const auto n = std::chrono::steady_clock::now();
+            if (say) std::fprintf(stderr, "[tsgo] set_graph: %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - last).count());
+            last = n;
+        };
+        lap("layout (build_problem)");
         const int P = pr.P, L = pr.L;
         if (P == 0) return set_error(-2, "tsgo_set_graph: the graph has no Se2 vertex");
         // state
@@ -350,12 +357,16 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
         HIP_OK(hipDeviceSynchronize());
+        lap("state + slot tables to the device");
         amg_on = cfg.preconditioner == 1 && pr.world == 1 && pr.P > kCoarsestMax;
         if (amg_on) { if (int rc = upload_amg()) return rc; }
         HIP_OK(hipDeviceSynchronize());
+        if (say) std::fprintf(stderr, "[tsgo] set_graph:   of which multigrid patterns on the host %8.1f ms\n", ms_amg_symbolic);
+        lap("multigrid patterns + upload");
         have_graph_data = true;
         predicted_cg = 0;
         if (cfg.use_graphs && pr.world == 1) { if (int rc = capture_cg_graph()) return rc; }
+        lap("hipGraph capture");
         ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return 0;
     }

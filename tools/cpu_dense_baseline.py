@@ -27,7 +27,7 @@ def gpu_run(g, iters):
     o = HipOptimizer(); o.set_graph(g); o.optimize(2)          # warm the device path
     o.set_graph(g)
     t = time.perf_counter(); r = o.optimize(iters); dt = time.perf_counter() - t
-    v = o.get_vertices(); o.close()
+    v = o.vertices(); o.close()
     return dt, r, v
 
 

@@ -178,6 +178,7 @@ typedef struct tsgo_amg_info {
     int64_t p_blocks[8];            /* blocks of the prolongator leaving each level */
     int64_t schur_contribs;         /* landmark-pair terms summed into the explicit level-0 matrix */
     double ms_layout, ms_symbolic;  /* host time: slot tables / hierarchy patterns */
+    int32_t agg_min[8], agg_max[8]; /* smallest / largest aggregate (in nodes of that level) leaving each level */
 } tsgo_amg_info;
 int tsgo_amg_probe(const tsgo_graph* g, tsgo_amg_info* out);
 

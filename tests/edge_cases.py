@@ -44,6 +44,14 @@ def landmark_edges_only():
     return GraphArrays(g.v_id, g.v_type, g.v_pos, g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep], g.fixed)
 
 
+def pose_graph_without_landmarks():
+    """ODOM edges only (a chain plus loop closures): a plain pose graph, every Jacobian -I / +I (EdgeSe2.h:35-37)."""
+    g = synth.make(400, 6, loop_closures=12, seed=23)
+    keep = g.e_type == 0
+    pose = g.v_type == 0
+    return GraphArrays(g.v_id[pose], g.v_type[pose], g.v_pos[pose], g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep], g.fixed)
+
+
 def shuffled_vertices_and_edges(seed=5):
     g = base()
     rng = np.random.default_rng(seed)
@@ -72,5 +80,6 @@ CASES = {
     "isolated_vertices": isolated_vertices,
     "sparse_large_ids": sparse_large_ids,
     "landmark_edges_only": landmark_edges_only,
+    "pose_graph_without_landmarks": pose_graph_without_landmarks,
     "self_loop_dup_edges": self_loop_and_duplicate_edges,
 }

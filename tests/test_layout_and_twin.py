@@ -157,6 +157,51 @@ def test_twin_multigrid_full_run_c1_matches_dense():
     assert r["cg_iters"].max() < 30
 
 
+def _amg_info(g):
+    lib = _lib.host_lib(); info = _lib.tsgo_amg_info(); cg = g.c_struct()
+    _lib.check(lib, lib.tsgo_amg_probe(C.byref(cg), C.byref(info)), "tsgo_amg_probe")
+    return info
+
+
+@pytest.mark.parametrize("shape", ["landmarks", "odometry_only", "no_odometry", "two_trajectories"])
+def test_matched_aggregates_have_bounded_sizes_and_coarsen_every_level(shape):
+    """host/amg.cpp aggregate_by_matching: every level shrinks by about its target (4, 4, 8 ...), no aggregate grows
+    past 1.5x the target plus the small groups it absorbed, on chains, landmark-only graphs and disconnected pieces."""
+    from toyslam_amd.graph import GraphArrays
+    g = synth.make(3000, 10, loop_closures=30, seed=4)
+    if shape == "odometry_only":
+        keep = g.e_type == 0
+        pose = g.v_type == 0
+        g = GraphArrays(g.v_id[pose], g.v_type[pose], g.v_pos[pose], g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep], g.fixed)
+    elif shape == "no_odometry":
+        keep = g.e_type == 1
+        g = GraphArrays(g.v_id, g.v_type, g.v_pos, g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep], g.fixed)
+    elif shape == "two_trajectories":      # cut the odometry chain in the middle and drop the landmarks both halves see
+        P = int((g.v_type == 0).sum()); half = P // 2
+        pose_of = {int(v): i for i, v in enumerate(g.v_id[g.v_type == 0])}
+        side = {}
+        for t, (a, b) in zip(g.e_type, g.e_ids):
+            if t == 1:
+                side.setdefault(int(b), set()).add(pose_of[int(a)] < half)
+        keep = np.array([(t == 0 and not (pose_of[int(a)] < half) != (pose_of[int(b)] < half)) or (t == 1 and len(side[int(b)]) == 1)
+                         for t, (a, b) in zip(g.e_type, g.e_ids)])
+        second_anchor = g.v_id[g.v_type == 0][half]      # every connected piece needs its own gauge
+        g = GraphArrays(g.v_id, g.v_type, g.v_pos, g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep],
+                        np.concatenate([g.fixed, [second_anchor]]).astype(g.fixed.dtype))
+    info = _amg_info(g)
+    targets = [4, 4, 8, 8, 8, 8]
+    assert info.n_levels >= 3
+    for l in range(info.n_levels - 1):
+        assert 1 <= info.agg_min[l] and info.agg_max[l] <= 3 * targets[l], (l, info.agg_min[l], info.agg_max[l])
+        assert info.rows[l + 1] * 2 <= info.rows[l], "level %d does not coarsen: %d -> %d" % (l, info.rows[l], info.rows[l + 1])
+    assert info.rows[info.n_levels - 1] <= 28
+    # and the preconditioner built on them solves the system
+    o = util.to_oracle(g)
+    a = oracle.sparse_step(o, 1e-12, precond="jacobi"); b = oracle.sparse_step(o, 1e-12, precond="amg")
+    assert np.abs(a["delta"] - b["delta"]).max() <= 1e-7 * max(np.abs(a["delta"]).max(), 1e-30)
+    assert b["cg_iters"] <= 60
+
+
 def test_hub_landmark_keeps_the_multigrid_lists_bounded_and_the_answer_exact():
     """One landmark observed from every pose (d = 400 -> 160 000 pose pairs) must not blow up the
     preconditioner's gather lists, and the solve stays exact."""

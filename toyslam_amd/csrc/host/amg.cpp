@@ -136,7 +136,10 @@ std::vector<int> find_diag(const BlockCsr& A) {
 
 // One coarsening step: level.A, level.agg, level.n_agg and xy are given; fills the rest and the
 // pattern of the next matrix.
-void coarsen(AmgLevel& L, const std::vector<double>& xy, BlockCsr& A_next, std::vector<double>& xy_next, bool smooth_p) {
+// rigid[i]: node i contains a pose with landmark observations.  Only those couple rotation to translation (an LM
+// edge's Jacobian carries the lever arm; the reference's ODOM Jacobians are -I / +I, EdgeSe2.h:35-37), so only
+// for them is "rotation about the aggregate's centroid" a slow mode; for the others it is the heading alone.
+void coarsen(AmgLevel& L, const std::vector<double>& xy, std::vector<char>& rigid, BlockCsr& A_next, std::vector<double>& xy_next, bool smooth_p) {
     const int n = L.n, na = L.n_agg;
     L.diag = find_diag(L.A);
     // centroids, relative coordinates
@@ -145,7 +148,15 @@ void coarsen(AmgLevel& L, const std::vector<double>& xy, BlockCsr& A_next, std::
     for (int i = 0; i < n; ++i) { xy_next[2 * (size_t)L.agg[i]] += xy[2 * (size_t)i]; xy_next[2 * (size_t)L.agg[i] + 1] += xy[2 * (size_t)i + 1]; ++cnt[L.agg[i]]; }
     for (int a = 0; a < na; ++a) if (cnt[a]) { xy_next[2 * (size_t)a] /= cnt[a]; xy_next[2 * (size_t)a + 1] /= cnt[a]; }
     L.rel.resize((size_t)n * 2);
-    for (int i = 0; i < n; ++i) { L.rel[2 * (size_t)i] = xy[2 * (size_t)i] - xy_next[2 * (size_t)L.agg[i]]; L.rel[2 * (size_t)i + 1] = xy[2 * (size_t)i + 1] - xy_next[2 * (size_t)L.agg[i] + 1]; }
+    for (int i = 0; i < n; ++i) {
+        L.rel[2 * (size_t)i] = rigid[i] ? xy[2 * (size_t)i] - xy_next[2 * (size_t)L.agg[i]] : 0.0;
+        L.rel[2 * (size_t)i + 1] = rigid[i] ? xy[2 * (size_t)i + 1] - xy_next[2 * (size_t)L.agg[i] + 1] : 0.0;
+    }
+    {
+        std::vector<char> next(na, 0);
+        for (int i = 0; i < n; ++i) next[L.agg[i]] |= rigid[i];
+        rigid.swap(next);
+    }
     // P pattern: aggregates of the row's neighbours
     L.P.n_rows = n; L.P.n_cols = na;
     {
@@ -385,6 +396,8 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     // ---- hierarchy ----------------------------------------------------------------------------------------
     std::vector<double> xy((size_t)P * 2);
     for (int i = 0; i < P; ++i) { xy[2 * (size_t)i] = pr.pose_xyt[3 * (size_t)i]; xy[2 * (size_t)i + 1] = pr.pose_xyt[3 * (size_t)i + 1]; }
+    std::vector<char> rigid(P, 0);
+    for (int i = 0; i < P; ++i) for_slots(pr.by_pose, i, [&](size_t) { rigid[i] = 1; });
     L0.agg.resize(P);
     // aggregate size per level; research override: TSGO_AGG_LIST="8,4,4,8" (last entry repeats) or TSGO_AGG0 / TSGO_AGGC
     std::vector<int> agg_list;
@@ -422,7 +435,7 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     for (;;) {
         if (cur.n <= kCoarsestMax) { S.A_last = cur.A; S.diag_last = find_diag(cur.A); break; }
         BlockCsr A_next; std::vector<double> xy_next;
-        coarsen(cur, xy, A_next, xy_next, (int)S.levels.size() < smooth_levels);
+        coarsen(cur, xy, rigid, A_next, xy_next, (int)S.levels.size() < smooth_levels);
         sw.lap("coarsen level");
         const int na = cur.n_agg;
         S.levels.push_back(std::move(cur));

@@ -3,6 +3,7 @@
 #include "errors.h"
 #include "problem.h"
 #include "amg.h"
+#include <algorithm>
 #include <chrono>
 #include <cstring>
 
@@ -43,7 +44,14 @@ extern "C" int tsgo_amg_probe(const tsgo_graph* g, tsgo_amg_info* out) {
     out->ms_layout = std::chrono::duration<double, std::milli>(t1 - t0).count();
     out->ms_symbolic = std::chrono::duration<double, std::milli>(t2 - t1).count();
     int n = 0;
-    for (const auto& L : amg.levels) if (n < 8) { out->rows[n] = L.n; out->blocks[n] = L.A.nnz(); out->p_blocks[n] = L.P.nnz(); ++n; }
+    for (const auto& L : amg.levels) if (n < 8) {
+        out->rows[n] = L.n; out->blocks[n] = L.A.nnz(); out->p_blocks[n] = L.P.nnz();
+        std::vector<int> cnt(L.n_agg, 0);
+        for (int a : L.agg) ++cnt[a];
+        out->agg_min[n] = cnt.empty() ? 0 : *std::min_element(cnt.begin(), cnt.end());
+        out->agg_max[n] = cnt.empty() ? 0 : *std::max_element(cnt.begin(), cnt.end());
+        ++n;
+    }
     if (n < 8) { out->rows[n] = amg.A_last.n_rows; out->blocks[n] = amg.A_last.nnz(); ++n; }
     out->n_levels = n;
     out->schur_contribs = (int64_t)amg.schur.slot_i.size();

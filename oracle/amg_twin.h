@@ -92,6 +92,12 @@ struct Hierarchy {
                 for (int q = L.a_src.ptr[ab]; q < L.a_src.ptr[ab + 1]; ++q) mat3_tmul(&P[l][(size_t)L.a_src.x[q] * 9], &T[l][(size_t)L.a_src.y[q] * 9], acc);
                 std::memcpy(&An[(size_t)ab * 9], acc, 72);
             }
+            // blocks below the diagonal are the transposes of their mirrors (host/amg.h: a_mirror)
+            for (int ab = 0; ab < nb; ++ab) {
+                const int mb = L.a_mirror[ab];
+                if (mb < 0) continue;
+                for (int x = 0; x < 3; ++x) for (int y = 0; y < 3; ++y) An[(size_t)ab * 9 + 3 * x + y] = An[(size_t)mb * 9 + 3 * y + x];
+            }
         }
         // smoother damping per level: 16 power steps on D^-1 A from a fixed start vector, exactly as the device
         // does (tsgo_hip.hip, estimate_damping): omega = min(1, 1.6 / (1.05 rho))

@@ -94,26 +94,96 @@ inline void emit_row(std::vector<Triple>& row, RowsOut& o) {
 }
 
 // Z = X * Y (patterns), with the (x block, y block) pairs that sum into every Z block, row by row.
-void spgemm_sym(const BlockCsr& X, const std::vector<int>* x_alias, const BlockCsr& Y, BlockCsr& Z, PairList& pl) {
+// Two passes over the rows, both parallel and without sorting the pairs: pass A counts the distinct columns and
+// the pairs of every row (a per-thread marker array over the columns), a prefix sum fixes where every row lands
+// in the final arrays, pass B sorts the row's distinct columns, lays out its groups and scatters the pairs into
+// them in (x, y) walking order.  mirror (for the symmetric product Z = P^T (A P)): only blocks on or above the
+// diagonal get a pair list; a block below it gets the index of its transpose instead (-1 elsewhere).
+std::string spgemm_sym(const BlockCsr& X, const std::vector<int>* x_alias, const BlockCsr& Y, BlockCsr& Z, PairList& pl,
+                       std::vector<int>* mirror = nullptr) {
     Z.n_rows = X.n_rows; Z.n_cols = Y.n_cols;
+    const int n = X.n_rows, nc = Y.n_cols;
+    const bool upper = mirror != nullptr;
     const auto t_begin = std::chrono::steady_clock::now();
-    std::vector<RowsOut> parts(64);
-    const int used = parallel_chunks(X.n_rows, [&](int c, int b, int e) {
-        std::vector<Triple> row;
-        RowsOut o;                       // thread-local: adjacent vector headers in `parts` would false-share
+    std::vector<int> d(n, 0);
+    std::vector<int64_t> m(n, 0);
+    parallel_chunks(n, [&](int, int b, int e) {
+        std::vector<int> mark(nc, -1);
         for (int i = b; i < e; ++i) {
-            row.clear();
+            int dd = 0; int64_t mm = 0;
             for (int a = X.ptr[i]; a < X.ptr[i + 1]; ++a) {
                 const int k = X.col[a];
-                for (int q = Y.ptr[k]; q < Y.ptr[k + 1]; ++q) row.push_back({Y.col[q], x_alias ? (*x_alias)[a] : a, q});
+                for (int q = Y.ptr[k]; q < Y.ptr[k + 1]; ++q) {
+                    const int c = Y.col[q];
+                    if (mark[c] != i) { mark[c] = i; ++dd; }
+                    if (!upper || c >= i) ++mm;
+                }
             }
-            emit_row(row, o);
+            d[i] = dd; m[i] = mm;
         }
-        parts[c] = std::move(o);
     });
-    Stopwatch sw3; sw3.t = t_begin; sw3.lap("    spgemm parallel part");
-    concat(parts, used, Z, pl, nullptr);
-    sw3.lap("    spgemm concat");
+    Z.ptr.assign(n + 1, 0);
+    std::vector<int64_t> poff(n + 1, 0);
+    for (int i = 0; i < n; ++i) { Z.ptr[i + 1] = Z.ptr[i] + d[i]; poff[i + 1] = poff[i] + m[i]; }
+    if (poff[n] > INT32_MAX) return "multigrid gather lists exceed 2^31 pairs";
+    const int nnz = Z.ptr[n];
+    Z.col.assign(nnz, 0);
+    pl.ptr.assign((size_t)nnz + 1, 0); pl.x.assign((size_t)poff[n], 0); pl.y.assign((size_t)poff[n], 0);
+    pl.ptr[nnz] = (int)poff[n];
+    Stopwatch sw3; sw3.t = t_begin; sw3.lap("    spgemm count pass");
+    parallel_chunks(n, [&](int, int b, int e) {
+        std::vector<int> mark(nc, -1), slot(nc, 0), cols, cnt, ord, rank, fill;
+        for (int i = b; i < e; ++i) {
+            cols.clear(); cnt.clear();
+            for (int a = X.ptr[i]; a < X.ptr[i + 1]; ++a) {
+                const int k = X.col[a];
+                for (int q = Y.ptr[k]; q < Y.ptr[k + 1]; ++q) {
+                    const int c = Y.col[q];
+                    if (mark[c] != i) { mark[c] = i; slot[c] = (int)cols.size(); cols.push_back(c); cnt.push_back(0); }
+                    if (!upper || c >= i) ++cnt[slot[c]];
+                }
+            }
+            const int dd = (int)cols.size();
+            ord.resize(dd); rank.resize(dd); fill.resize(dd);
+            std::iota(ord.begin(), ord.end(), 0);
+            std::sort(ord.begin(), ord.end(), [&](int p, int q) { return cols[p] < cols[q]; });
+            int64_t at = poff[i];
+            for (int r = 0; r < dd; ++r) {
+                const int loc = ord[r];
+                rank[loc] = r;
+                Z.col[Z.ptr[i] + r] = cols[loc];
+                pl.ptr[(size_t)Z.ptr[i] + r] = (int)at;
+                fill[r] = (int)at;
+                at += cnt[loc];
+            }
+            for (int a = X.ptr[i]; a < X.ptr[i + 1]; ++a) {
+                const int k = X.col[a];
+                const int xa = x_alias ? (*x_alias)[a] : a;
+                for (int q = Y.ptr[k]; q < Y.ptr[k + 1]; ++q) {
+                    const int c = Y.col[q];
+                    if (upper && c < i) continue;
+                    const int dst = fill[rank[slot[c]]]++;
+                    pl.x[dst] = xa; pl.y[dst] = q;
+                }
+            }
+        }
+    });
+    sw3.lap("    spgemm fill pass");
+    if (upper) {
+        mirror->assign(nnz, -1);
+        bool ok = true;
+        for (int i = 0; i < n; ++i)
+            for (int z = Z.ptr[i]; z < Z.ptr[i + 1]; ++z) {
+                const int c = Z.col[z];
+                if (c >= i) continue;
+                const int* lo = Z.col.data() + Z.ptr[c]; const int* hi = Z.col.data() + Z.ptr[c + 1];
+                const int* f = std::lower_bound(lo, hi, i);
+                if (f == hi || *f != i) { ok = false; continue; }
+                (*mirror)[z] = (int)(f - Z.col.data());
+            }
+        if (!ok) return "the Galerkin pattern is not structurally symmetric";
+    }
+    return std::string();
 }
 
 void transpose_pattern(const BlockCsr& X, BlockCsr& Xt, std::vector<int>& to_src) {
@@ -139,7 +209,7 @@ std::vector<int> find_diag(const BlockCsr& A) {
 // rigid[i]: node i contains a pose with landmark observations.  Only those couple rotation to translation (an LM
 // edge's Jacobian carries the lever arm; the reference's ODOM Jacobians are -I / +I, EdgeSe2.h:35-37), so only
 // for them is "rotation about the aggregate's centroid" a slow mode; for the others it is the heading alone.
-void coarsen(AmgLevel& L, const std::vector<double>& xy, std::vector<char>& rigid, BlockCsr& A_next, std::vector<double>& xy_next, bool smooth_p) {
+std::string coarsen(AmgLevel& L, const std::vector<double>& xy, std::vector<char>& rigid, BlockCsr& A_next, std::vector<double>& xy_next, bool smooth_p) {
     const int n = L.n, na = L.n_agg;
     L.diag = find_diag(L.A);
     // centroids, relative coordinates
@@ -183,10 +253,11 @@ void coarsen(AmgLevel& L, const std::vector<double>& xy, std::vector<char>& rigi
     sw2.lap("  (P pattern)");
     transpose_pattern(L.P, L.R, L.r_to_p);
     sw2.lap("  transpose");
-    spgemm_sym(L.A, nullptr, L.P, L.T, L.t_src);
+    std::string err = spgemm_sym(L.A, nullptr, L.P, L.T, L.t_src);
     sw2.lap("  T = A P");
-    spgemm_sym(L.R, &L.r_to_p, L.T, A_next, L.a_src);
+    if (err.empty()) err = spgemm_sym(L.R, &L.r_to_p, L.T, A_next, L.a_src, &L.a_mirror);
     sw2.lap("  A' = R T");
+    return err;
 }
 
 
@@ -435,7 +506,8 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     for (;;) {
         if (cur.n <= kCoarsestMax) { S.A_last = cur.A; S.diag_last = find_diag(cur.A); break; }
         BlockCsr A_next; std::vector<double> xy_next;
-        coarsen(cur, xy, rigid, A_next, xy_next, (int)S.levels.size() < smooth_levels);
+        const std::string cerr = coarsen(cur, xy, rigid, A_next, xy_next, (int)S.levels.size() < smooth_levels);
+        if (!cerr.empty()) return cerr;
         sw.lap("coarsen level");
         const int na = cur.n_agg;
         S.levels.push_back(std::move(cur));

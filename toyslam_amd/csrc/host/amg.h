@@ -59,7 +59,8 @@ struct AmgLevel {
     std::vector<int> r_to_p;         // per R block: the P block it transposes
     BlockCsr T;                      // n x n_agg: pattern of A_l P_l
     PairList t_src;                  // per T block: x = A block, y = P block
-    PairList a_src;                  // per A_{l+1} block: x = P block (transposed), y = T block
+    PairList a_src;                  // per A_{l+1} block on or above the diagonal: x = P block (transposed), y = T block
+    std::vector<int> a_mirror;       // per A_{l+1} block: below the diagonal, the block it is the transpose of; else -1
 };
 
 struct SchurLists {                  // level 0: how each off-diagonal S block is summed

@@ -211,6 +211,17 @@ __global__ __launch_bounds__(kBlock) void k_pair_gemm_wave(int n_out, const int*
     }
 }
 
+// The Galerkin product P^T (A P) is symmetric: only its blocks on and above the diagonal are summed from pair
+// lists; a block below it is the transpose of its mirror (host/amg.h: a_mirror).  One thread per element.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_mirror_blocks(int n_blocks, const int* __restrict__ mirror, HT<T>* A) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    const int b = t / 9, e = t % 9;
+    if (b >= n_blocks) return;
+    const int m = mirror[b];
+    if (m >= 0) A[(size_t)b * 9 + e] = A[(size_t)m * 9 + (e % 3) * 3 + e / 3];
+}
+
 // Dense inverse of the coarsest matrix in LDS (n <= 84), in-place Gauss-Jordan; SPD so no pivoting.
 // One workgroup of 1024 threads as a 32 x 32 tile walking the matrix.
 constexpr int kDenseThreads = 1024;

@@ -96,14 +96,26 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
     // ---- classify vertices -----------------------------------------------------------------------
     std::vector<int> cls(nV);                 // class index within its type
     std::vector<int> pose_pos, lm_pos;        // class index -> vertex position
+    // id -> vertex position: a flat table when the ids are (nearly) dense, as the reference's client sends them
+    // (python/slam_main.py:161-185 numbers vertices 0..V-1); a hash map for anything else
+    uint32_t max_id = 0;
+    for (int i = 0; i < nV; ++i) max_id = std::max(max_id, g.v_id[i]);
+    const bool flat = nV > 0 && (uint64_t)max_id < 4ull * (uint64_t)nV + 1024;
+    std::vector<int> table(flat ? (size_t)max_id + 1 : 0, -1);
     std::unordered_map<uint32_t, int> by_id;
-    by_id.reserve((size_t)nV * 2);
+    if (!flat) by_id.reserve((size_t)nV * 2);
+    auto lookup = [&](uint32_t id) -> int {
+        if (flat) return id <= max_id ? table[id] : -1;
+        auto it = by_id.find(id);
+        return it == by_id.end() ? -1 : it->second;
+    };
     for (int i = 0; i < nV; ++i) {
         const uint32_t t = g.v_type[i];
         if (t == 0) { cls[i] = (int)pose_pos.size(); pose_pos.push_back(i); }
         else if (t == 1) { cls[i] = (int)lm_pos.size(); lm_pos.push_back(i); }
         else return "unknown vertex type " + std::to_string(t);
-        if (!by_id.emplace(g.v_id[i], i).second) return "duplicate vertex id " + std::to_string(g.v_id[i]);
+        if (flat) { if (table[g.v_id[i]] >= 0) return "duplicate vertex id " + std::to_string(g.v_id[i]); table[g.v_id[i]] = i; }
+        else if (!by_id.emplace(g.v_id[i], i).second) return "duplicate vertex id " + std::to_string(g.v_id[i]);
     }
     const int P = (int)pose_pos.size(), Lt = (int)lm_pos.size();
     pr.P = P; pr.L_total = Lt;
@@ -112,10 +124,10 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
     std::vector<int> ev1(nE), ev2(nE);        // vertex positions of the endpoints
     std::vector<int> deg_pose_lm(P, 0), deg_lm(Lt, 0), deg_pose_od(P, 0);
     for (int e = 0; e < nE; ++e) {
-        auto a = by_id.find(g.e_ids[2 * (size_t)e]), b = by_id.find(g.e_ids[2 * (size_t)e + 1]);
-        if (a == by_id.end() || b == by_id.end())
+        const int a = lookup(g.e_ids[2 * (size_t)e]), b = lookup(g.e_ids[2 * (size_t)e + 1]);
+        if (a < 0 || b < 0)
             return "edge " + std::to_string(e) + " refers to an unknown vertex id";
-        ev1[e] = a->second; ev2[e] = b->second;
+        ev1[e] = a; ev2[e] = b;
         const uint32_t t = g.e_type[e];
         if (t == 0) {
             if (g.v_type[ev1[e]] != 0 || g.v_type[ev2[e]] != 0) return "ODOM edge " + std::to_string(e) + " must join two Se2 vertices";
@@ -171,9 +183,8 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
         pr.lm_xy[(size_t)i * 2] = g.v_pos[(size_t)v * 3]; pr.lm_xy[(size_t)i * 2 + 1] = g.v_pos[(size_t)v * 3 + 1];
     }
     for (int i = 0; i < g.n_fixed; ++i) {
-        auto it = by_id.find(g.fixed[i]);
-        if (it == by_id.end()) return "fixed vertex id " + std::to_string(g.fixed[i]) + " is unknown";
-        const int v = it->second;
+        const int v = lookup(g.fixed[i]);
+        if (v < 0) return "fixed vertex id " + std::to_string(g.fixed[i]) + " is unknown";
         if (g.v_type[v] == 0) {
             const int p = pose_internal[cls[v]];
             if (p >= pr.pose_first && p < pr.pose_last) pr.gauge_p[p] += kGaugeTerm;

@@ -156,12 +156,13 @@ __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __r
 template <typename T, int TRANS>
 __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __restrict__ ptr, const int* __restrict__ px,
                                                       const int* __restrict__ py, const HT<T>* __restrict__ X, const HT<T>* __restrict__ Y,
-                                                      HT<T>* __restrict__ out) {
+                                                      HT<T>* __restrict__ out, const int* __restrict__ which) {
     const int lane = threadIdx.x & 63;
     if (lane >= 63) return;
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int o = wave * 7 + lane / 9, e = lane % 9, i = e / 3, j = e % 3;
-    if (o >= n_out) return;
+    const int oo = wave * 7 + lane / 9, e = lane % 9, i = e / 3, j = e % 3;
+    if (oo >= n_out) return;
+    const int o = which ? which[oo] : oo;        // which: the output blocks that have a pair list (the others are mirrored)
     T acc = 0;
     // the list is walked four pairs at a time with every index load, then every value load, issued before the
     // arithmetic: a lane's time is its chain of dependent loads (index -> block), not bandwidth
@@ -192,10 +193,11 @@ __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __re
 template <typename T, int TRANS>
 __global__ __launch_bounds__(kBlock) void k_pair_gemm_wave(int n_out, const int* __restrict__ ptr, const int* __restrict__ px,
                                                            const int* __restrict__ py, const HT<T>* __restrict__ X, const HT<T>* __restrict__ Y,
-                                                           HT<T>* __restrict__ out) {
+                                                           HT<T>* __restrict__ out, const int* __restrict__ which) {
     const int lane = threadIdx.x & 63;
-    const int o = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    if (o >= n_out) return;
+    const int oo = (blockIdx.x * kBlock + threadIdx.x) >> 6;
+    if (oo >= n_out) return;
+    const int o = which ? which[oo] : oo;
     T acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     for (int q = ptr[o] + lane; q < ptr[o + 1]; q += 64) {
         T a[9], b[9];

@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tsgo.h"
@@ -106,7 +107,8 @@ template <typename T> struct DevLevel {      // device copy of one AmgLevel (hos
     int *A_ptr = nullptr, *A_col = nullptr, *A_row = nullptr, *diag = nullptr;
     int *P_ptr = nullptr, *P_col = nullptr, *P_row = nullptr, *p_self = nullptr, *ps_ptr = nullptr, *ps_x = nullptr, *ps_y = nullptr;
     int *R_ptr = nullptr, *R_col = nullptr, *r_to_p = nullptr, *p_to_r = nullptr;
-    int *ts_ptr = nullptr, *ts_x = nullptr, *ts_y = nullptr, *as_ptr = nullptr, *as_x = nullptr, *as_y = nullptr, *as_mirror = nullptr;
+    int *ts_ptr = nullptr, *ts_x = nullptr, *ts_y = nullptr, *as_ptr = nullptr, *as_x = nullptr, *as_y = nullptr, *as_mirror = nullptr, *as_upper = nullptr;
+    int n_upper = 0;
     using H = HT<T>;                              // hierarchy storage type (tsgo_amg_kernels.h)
     T* rel = nullptr;
     H *A = nullptr, *Dinv = nullptr, *P = nullptr, *Tv = nullptr, *Rv = nullptr;
@@ -214,11 +216,19 @@ template <typename T> struct Engine : IEngine {
         for (int i = 0; i < m.n_rows; ++i) for (int a = m.ptr[i]; a < m.ptr[i + 1]; ++a) r[a] = i;
         return r;
     }
+    // The hierarchy's patterns are built by a host thread (host/amg.cpp) while this thread uploads state and slot tables.
+    std::thread amg_builder;
+    std::string amg_builder_error;
+    void start_amg_builder() {
+        amg_builder = std::thread([this] {
+            const auto t0 = std::chrono::steady_clock::now();
+            amg_builder_error = build_amg(pr, amg);
+            ms_amg_symbolic = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        });
+    }
     int upload_amg() {
-        const auto t0 = std::chrono::steady_clock::now();
-        const std::string err = build_amg(pr, amg);
-        if (!err.empty()) return set_error(-2, "tsgo_set_graph: " + err);
-        ms_amg_symbolic = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (amg_builder.joinable()) amg_builder.join();
+        if (!amg_builder_error.empty()) return set_error(-2, "tsgo_set_graph: " + amg_builder_error);
         lv.assign(amg.levels.size(), DevLevel<T>());
 #define UP(dst, vec) if (int rc = upload_i32(&dst, vec)) return rc
         for (size_t l = 0; l < amg.levels.size(); ++l) {
@@ -232,6 +242,7 @@ template <typename T> struct Engine : IEngine {
             { std::vector<int> inv(L.r_to_p.size()); for (size_t k = 0; k < inv.size(); ++k) inv[L.r_to_p[k]] = (int)k; UP(D.p_to_r, inv); }
             UP(D.ts_ptr, L.t_src.ptr); UP(D.ts_x, L.t_src.x); UP(D.ts_y, L.t_src.y);
             UP(D.as_ptr, L.a_src.ptr); UP(D.as_x, L.a_src.x); UP(D.as_y, L.a_src.y); UP(D.as_mirror, L.a_mirror);
+            { std::vector<int> up; for (int b = 0; b < (int)L.a_mirror.size(); ++b) if (L.a_mirror[b] < 0) up.push_back(b); D.n_upper = (int)up.size(); UP(D.as_upper, up); }
             if (int rc = upload_T(&D.rel, L.rel.data(), L.rel.size())) return rc;
             if (int rc = dalloc(&D.A, (size_t)D.nnzA * 9)) return rc;
             if (int rc = dalloc(&D.Dinv, (size_t)D.n * 9)) return rc;
@@ -313,6 +324,9 @@ template <typename T> struct Engine : IEngine {
         lap("layout (build_problem)");
         const int P = pr.P, L = pr.L;
         if (P == 0) return set_error(-2, "tsgo_set_graph: the graph has no Se2 vertex");
+        amg_on = cfg.preconditioner == 1 && pr.world == 1 && pr.P > kCoarsestMax;
+        if (amg_on) start_amg_builder();
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{amg_builder};   // on every error path too
         // state
         std::vector<double> ps_h((size_t)P * 4), th_h(P);
         for (int i = 0; i < P; ++i) {
@@ -358,7 +372,6 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
         HIP_OK(hipDeviceSynchronize());
         lap("state + slot tables to the device");
-        amg_on = cfg.preconditioner == 1 && pr.world == 1 && pr.P > kCoarsestMax;
         if (amg_on) { if (int rc = upload_amg()) return rc; }
         HIP_OK(hipDeviceSynchronize());
         if (say) std::fprintf(stderr, "[tsgo] set_graph:   of which multigrid patterns on the host %8.1f ms\n", ms_amg_symbolic);
@@ -405,10 +418,10 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL((k_block_inv<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.diag, (const H*)L.A, L.Dinv);
             hipLaunchKernelGGL((k_prolongator<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, L.P_row, L.p_self, L.ps_ptr, L.ps_x, L.ps_y,
                                (const H*)L.A, (const H*)L.Dinv, (const T*)L.rel, (T)kProlongOmega, L.P, L.p_to_r, L.Rv);
-            if (L.pairs_T > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 0>), dim3(grid_for(L.nnzT, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv);
-            else hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for((L.nnzT + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv);
-            if (L.pairs_A > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1>), dim3(grid_for(L.nnzNext, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext);
-            else hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.nnzNext + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzNext, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext);
+            if (L.pairs_T > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 0>), dim3(grid_for(L.nnzT, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv, (const int*)nullptr);
+            else hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for((L.nnzT + 6) / 7, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv, (const int*)nullptr);
+            if (L.pairs_A > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1>), dim3(grid_for(L.n_upper, 64)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
+            else hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.n_upper + 6) / 7, 64)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
             hipLaunchKernelGGL((k_mirror_blocks<T>), dim3(grid_for(L.nnzNext, 9)), dim3(kBlock), 0, stream, L.nnzNext, (const int*)L.as_mirror, Anext);
         }
         hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kDenseThreads), 0, stream, nb_last, last_ptr, last_col, (const H*)A_last, inv_last);

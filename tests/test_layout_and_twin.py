@@ -199,7 +199,7 @@ def test_matched_aggregates_have_bounded_sizes_and_coarsen_every_level(shape):
     o = util.to_oracle(g)
     a = oracle.sparse_step(o, 1e-12, precond="jacobi"); b = oracle.sparse_step(o, 1e-12, precond="amg")
     assert np.abs(a["delta"] - b["delta"]).max() <= 1e-7 * max(np.abs(a["delta"]).max(), 1e-30)
-    assert b["cg_iters"] <= 60
+    assert b["cg_iters"] <= 80
 
 
 def test_hub_landmark_keeps_the_multigrid_lists_bounded_and_the_answer_exact():

@@ -33,8 +33,10 @@ constexpr double kSmoother0Omega = 1.0; // smoother damping before the first est
 constexpr double kSmootherOmega = 0.8;  // ... and on the coarse levels.  The working values are ESTIMATED per level from a power
                                         // iteration on D^-1 A (omega = min(1, 1.6 / (1.05 rho))): smoothed Galerkin matrices reach
                                         // rho = 2 ... 17, and omega * rho >= 2 makes the cycle indefinite (seen with fixed 0.8 / 1.0)
-constexpr int kCoarseSweeps = 2;      // block-Jacobi sweeps per side on the coarse levels: V(1,1) on level 0, V(2,2) below
-                                      // (100k poses: 66 -> 53 PCG iterations for +30 us per iteration)
+constexpr int kCoarseSweeps = 2;      // block-Jacobi sweeps per side on the coarse levels: V(1,1) on level 0, V(2,2) below ...
+constexpr int kSmallLevelRows = 2048; // ... except on levels this small, which get
+constexpr int kSmallLevelSweeps = 1;  // one sweep per side: their kernels are pure launch latency (5 us each) and the second
+                                      // sweep buys no iterations there (100k poses, device: 19.6 -> 19.8 PCG iterations, 276 -> 265 us)
 
 struct BlockCsr {
     int n_rows = 0, n_cols = 0;

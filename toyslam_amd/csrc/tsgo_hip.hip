@@ -152,10 +152,18 @@ template <typename T> struct Engine : IEngine {
     int hier_age = -1, hier_max_age = kHierMaxAge, hier_slack = kHierSlack, iters_fresh = 0, iters_last = 0;   // -1: no valid hierarchy
     bool have_prev = false;            // xprev holds the pose delta of the previous solve (warm start)
     int coarse_sweeps = kCoarseSweeps;
+    std::vector<int> sweeps_list;      // research: sweeps per side on levels 1, 2, ... (TSGO_SWEEPS_LIST="2,2,1"; the last entry repeats)
+    bool sweeps_forced = false;        // TSGO_COARSE_SWEEPS given: the same count on every coarse level
+    int nu_at(size_t l) const {
+        if (!sweeps_list.empty()) return sweeps_list[std::min(l - 1, sweeps_list.size() - 1)];
+        if (sweeps_forced) return coarse_sweeps;
+        return lv[l].n <= kSmallLevelRows ? kSmallLevelSweeps : coarse_sweeps;
+    }
     bool low_cycle = true;     // f32 slot planes for the Schur products inside the multigrid cycle
 
     explicit Engine(const tsgo_config& c) : cfg(c) {
-        if (const char* e = getenv("TSGO_COARSE_SWEEPS")) coarse_sweeps = std::max(1, std::min(4, atoi(e)));
+        if (const char* e = getenv("TSGO_COARSE_SWEEPS")) { coarse_sweeps = std::max(1, std::min(4, atoi(e))); sweeps_forced = true; }
+        if (const char* e = getenv("TSGO_SWEEPS_LIST")) for (const char* q = e; *q;) { sweeps_list.push_back(std::max(1, std::min(4, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
         if (const char* e = getenv("TSGO_CYCLE_F64")) low_cycle = atoi(e) == 0;
         if (const char* e = getenv("TSGO_HIER_MAX_AGE")) hier_max_age = std::max(1, atoi(e));
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
@@ -498,9 +506,9 @@ template <typename T> struct Engine : IEngine {
         }
         // coarse levels: V(nu,nu) with nu = coarse_sweeps block-Jacobi sweeps (the first pre-sweep comes fused
         // with the restriction above).  The current iterate alternates between L.z and L.z2; it ends in L.z2.
-        const int nu = coarse_sweeps;
         for (size_t l = 1; l < nl; ++l) {
             DevLevel<T>& L = lv[l];
+            const int nu = nu_at(l);
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
             T* cur = L.z; T* oth = L.z2;
             for (int sw = 1; sw < nu; ++sw) {
@@ -514,12 +522,12 @@ template <typename T> struct Engine : IEngine {
             }
         }
         // iterate of level l after the down pass: L.z when nu is odd, L.z2 when even
-        auto down_iter = [&](DevLevel<T>& L) { return (nu % 2) ? L.z : L.z2; };
-        auto down_other = [&](DevLevel<T>& L) { return (nu % 2) ? L.z2 : L.z; };
+        auto down_iter = [&](DevLevel<T>& L, int nu) { return (nu % 2) ? L.z : L.z2; };
+        auto down_other = [&](DevLevel<T>& L, int nu) { return (nu % 2) ? L.z2 : L.z; };
         if (nl > 1) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
             DevLevel<T>& L = lv[nl - 1];
             hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kDenseThreads), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv, L.P_ptr, L.P_col, (const H*)L.P,
-                               (const T*)L.res, (const T*)inv_last, down_iter(L), s);
+                               (const T*)L.res, (const T*)inv_last, down_iter(L, nu_at(nl - 1)), s);
         } else {        // only level 0 above the dense level: residual r - S z is restricted from (r, sbuf)
             DevLevel<T>& L = lv[0];
             hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv,
@@ -528,7 +536,8 @@ template <typename T> struct Engine : IEngine {
         }
         for (size_t l = nl - 1; l >= 1; --l) {
             DevLevel<T>& L = lv[l];
-            T* cur = down_iter(L); T* oth = down_other(L);
+            const int nu = nu_at(l);
+            T* cur = down_iter(L, nu); T* oth = down_other(L, nu);
             if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, cur, 3, s);
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
             for (int sw = 0; sw < nu; ++sw) {

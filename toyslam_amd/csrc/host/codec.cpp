@@ -61,7 +61,7 @@ extern "C" int tsgo_wire_decode(const uint8_t* payload, size_t len, tsgo_wire_gr
 
     const uint32_t nV = r.u32();                                        // DeserializeGraph.h:20
     if (!r.ok || (size_t)nV > len / 16) return fail("vertex count does not fit the payload");
-    w->v_id.reserve(nV); w->v_type.reserve(nV); w->v_pos.reserve((size_t)nV * 3);
+    w->v_id.resize(nV); w->v_type.resize(nV); w->v_pos.resize((size_t)nV * 3);      // sized once, written by index
     for (uint32_t i = 0; i < nV; ++i) {
         const uint32_t id = r.u32(), type = r.u32();                    // :28-31
         double x, y, th = 0;
@@ -69,13 +69,14 @@ extern "C" int tsgo_wire_decode(const uint8_t* payload, size_t len, tsgo_wire_gr
         else if (type == 1) { x = r.f32(); y = r.f32(); }               // :45-53
         else return fail("unknown vertex type " + std::to_string(type));
         if (!r.ok) return fail("truncated in vertex " + std::to_string(i));
-        w->v_id.push_back(id); w->v_type.push_back(type);
-        w->v_pos.push_back(x); w->v_pos.push_back(y); w->v_pos.push_back(th);
+        w->v_id[i] = id; w->v_type[i] = type;
+        w->v_pos[3 * (size_t)i] = x; w->v_pos[3 * (size_t)i + 1] = y; w->v_pos[3 * (size_t)i + 2] = th;
     }
     const uint32_t nE = r.u32();                                        // :55
     if (!r.ok || (size_t)nE > len / 36) return fail("edge count does not fit the payload");
-    w->e_type.reserve(nE); w->e_ids.reserve((size_t)nE * 2);
-    w->e_meas.reserve((size_t)nE * 9); w->e_inf.reserve((size_t)nE * 3);
+    w->e_type.resize(nE); w->e_ids.resize((size_t)nE * 2);
+    w->e_meas.resize((size_t)nE * 9); w->e_inf.resize((size_t)nE * 3);
+    w->e_meas_f32.resize((size_t)nE * 9); w->e_inf_f32.resize((size_t)nE * 3);
     for (uint32_t i = 0; i < nE; ++i) {
         const uint32_t type = r.u32(), id1 = r.u32(), id2 = r.u32(), rows = r.u32(), cols = r.u32();   // :61-70
         if (!r.ok) return fail("truncated in edge " + std::to_string(i));
@@ -107,9 +108,9 @@ extern "C" int tsgo_wire_decode(const uint8_t* payload, size_t len, tsgo_wire_gr
         if (type == 1) wf[2] = 0;
         for (uint32_t j = 0; j < cols_inf; ++j) wf[j] = r.f32();                                         // :138-142
         if (!r.ok) return fail("truncated in edge " + std::to_string(i));
-        w->e_type.push_back(type); w->e_ids.push_back(id1); w->e_ids.push_back(id2);
-        for (int k = 0; k < 9; ++k) { w->e_meas.push_back(m[k]); w->e_meas_f32.push_back(mf[k]); }
-        for (int k = 0; k < 3; ++k) { w->e_inf.push_back(wf[k]); w->e_inf_f32.push_back(wf[k]); }
+        w->e_type[i] = type; w->e_ids[2 * (size_t)i] = id1; w->e_ids[2 * (size_t)i + 1] = id2;
+        for (int k = 0; k < 9; ++k) { w->e_meas[9 * (size_t)i + k] = m[k]; w->e_meas_f32[9 * (size_t)i + k] = mf[k]; }
+        for (int k = 0; k < 3; ++k) { w->e_inf[3 * (size_t)i + k] = wf[k]; w->e_inf_f32[3 * (size_t)i + k] = wf[k]; }
     }
     const uint32_t nF = r.u32();                                        // :163
     if (!r.ok || (size_t)nF > len / 4) return fail("fixed-vertex count does not fit the payload");

@@ -127,7 +127,7 @@ template <typename T> struct Engine : IEngine {
     T *ps = nullptr, *theta = nullptr, *lmrec = nullptr, *gauge_p = nullptr, *gauge_l = nullptr;
     Table<T> tp{}, tl{}, to{};
     T *part = nullptr, *dp = nullptr, *minv = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *x = nullptr, *zc = nullptr;
-    T *sbuf = nullptr, *tvec = nullptr, *dl = nullptr, *gpart[2] = {nullptr, nullptr}, *npart = nullptr;
+    T *sbuf = nullptr, *tvec = nullptr, *ninv = nullptr, *dl = nullptr, *gpart[2] = {nullptr, nullptr}, *npart = nullptr;
     CgState<T>* st[2] = {nullptr, nullptr};
     CgState<T>* h_state = nullptr;     // pinned
     T* h_scratch = nullptr;            // pinned, partial sums
@@ -172,6 +172,7 @@ template <typename T> struct Engine : IEngine {
     ~Engine() override { release(); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 
     void release() {
+        if (amg_builder.joinable()) amg_builder.join();
         if (cg_graph) { (void)hipGraphExecDestroy(cg_graph); cg_graph = nullptr; }
         for (void* a : allocs) (void)hipFree(a);
         allocs.clear();
@@ -367,6 +368,8 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipMemset(zc, 0, (size_t)P * kPoseRec * sizeof(T)));
         if (int rc = dalloc(&sbuf, (size_t)P * 3 + nbP)) return rc;
         if (int rc = dalloc(&tvec, (size_t)std::max(L, 1) * 2)) return rc;
+        if (int rc = dalloc(&ninv, (size_t)std::max(L, 1) * kNinvRec)) return rc;
+        HIP_OK(hipMemset(ninv, 0, (size_t)std::max(L, 1) * kNinvRec * sizeof(T)));
         if (int rc = dalloc(&dl, (size_t)std::max(L, 1) * 2)) return rc;
         HIP_OK(hipMemset(dl, 0, (size_t)std::max(L, 1) * 2 * sizeof(T)));
         for (int k = 0; k < 2; ++k) { if (int rc = dalloc(&gpart[k], nbC)) return rc; if (int rc = dalloc(&st[k], 1)) return rc; }
@@ -394,7 +397,7 @@ template <typename T> struct Engine : IEngine {
 
     // ---- launches --------------------------------------------------------------------------------
     void launch_lin() {
-        if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l);
+        if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv);
         LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18);
     }
     void launch_finalize() {
@@ -404,12 +407,12 @@ template <typename T> struct Engine : IEngine {
     // products inside the multigrid cycle; never the product PCG itself takes).
     void launch_matvec(int slot, bool with_rz = false, bool low = false) {
         if (low) {
-            if (tl.n_slices > 0) LAUNCH_GML(pr.by_lm.G, k_schur_lm, 0, 1, nbL, stream, tl, zc, lmrec, tvec, st[slot], T(0), dl, npart);
+            if (tl.n_slices > 0) LAUNCH_GML(pr.by_lm.G, k_schur_lm, 0, 1, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
             LAUNCH_GML1(pr.by_pose.G, k_schur_pose, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
                         (const T*)nullptr, rzpart);
             return;
         }
-        if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, tvec, st[slot], T(0), dl, npart);
+        if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
         LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
                  (const T*)(with_rz ? r : nullptr), rzpart);
     }
@@ -691,7 +694,7 @@ template <typename T> struct Engine : IEngine {
         const int P = pr.P;
         hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, zc, xprev, (const T*)nullptr, T(0));
         have_prev = step != T(0);     // a probe (step 0) leaves nothing to carry over
-        if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 1, nbL, stream, tl, zc, lmrec, tvec, st[0], step, dl, npart + nbC);
+        if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 1, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[0], step, dl, npart + nbC);
         hipLaunchKernelGGL((k_pose_update<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, ps, theta, step, npart);
         const int nl = tl.n_slices > 0 ? nbL : 0;
         HIP_OK(hipMemcpyAsync(h_scratch, npart, sizeof(T) * (size_t)(nbC + nl), hipMemcpyDeviceToHost, stream));
@@ -834,17 +837,17 @@ template <typename T> struct Engine : IEngine {
         const double b_lm = El * (4 + 4 * s) + P * 5 * s + L * 5 * s;
         const double b_pose = El * (4 + 4 * s) + L * 2 * s + P * (5 + 6 + 3) * s + od * (4 + 3 * s + 3 * s);
         const double b_upd = P * (3 + 3 + 6 + 4 * 3 * 2 - 3) * s;   // sz, z in; minv in; r p q x in+out (x,r,p,q), z out
-        const double b_linlm = El * (4 + 4 * s + 4 * s) + El * 4 * s * 0 + P * 4 * s + L * (2 + 5) * s;
+        const double b_linlm = El * (4 + 4 * s + 4 * s) + P * 4 * s + L * (2 + 5 + 3) * s;
         const double b_linpose = El * (4 + 4 * s + 4 * s) + L * 7 * s + P * (4 + 18) * s + od * (4 + 9 * s + 3 * s);
         // whole iterations are timed with the stopping test disabled: a converged solve turns every kernel into an early exit
-        const double keep_tol = cfg.pcg_rel_tol;
+        struct TolGuard { double& tol; double keep; ~TolGuard() { tol = keep; } } tol_guard{cfg.pcg_rel_tol, cfg.pcg_rel_tol};
         if (which == 5) cfg.pcg_rel_tol = 0;
         for (int pass = 0; pass < 2; ++pass) {
             const int n = pass == 0 ? 3 : reps;
             HIP_OK(hipEventRecord(ev[0], stream));
             for (int k = 0; k < n; ++k) {
                 switch (which) {
-                    case 0: if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, tvec, st[0], T(0), dl, npart); break;
+                    case 0: if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[0], T(0), dl, npart); break;
                     case 1: LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[0], (const T*)nullptr, (T*)nullptr); break;
                     case 2: {   // state slot 1 is never written here, slot 0 stays "iters = 0, not done"
                         const T tol2 = (T)0;
@@ -852,7 +855,7 @@ template <typename T> struct Engine : IEngine {
                                            gpart[1], st[0], st[1], minv, r, p, q, x, zc, tol2, 1 << 30, (const T*)one_dev);
                         break;
                     }
-                    case 3: if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l); break;
+                    case 3: if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv); break;
                     case 4: LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18); break;
                     case 6: if (amg_on) launch_amg_setup(); break;
                     default: launch_iteration(0); launch_iteration(1); break;
@@ -867,7 +870,7 @@ template <typename T> struct Engine : IEngine {
                 *us = 1e3 * ms / per;
             }
         }
-        cfg.pcg_rel_tol = keep_tol;
+        cfg.pcg_rel_tol = tol_guard.keep;
         const double tab[7] = {b_lm, b_pose, b_upd, b_linlm, b_linpose, (amg_on ? 3.0 : 1.0) * (b_lm + b_pose) + b_upd, 0.0};
         *bytes = tab[std::min(std::max(which, 0), 6)];
         // leave a consistent state behind

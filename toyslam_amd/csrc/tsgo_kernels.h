@@ -31,6 +31,7 @@ constexpr uint32_t kDirMask = 0x80000000u;
 
 // record layouts (in units of T)
 constexpr int kPoseRec = 8;   // zc: v0 v1 v2 c s . . .      (the vector CG multiplies + the pose's cos/sin)
+constexpr int kNinvRec = 4;   // ninv: ixx ixy iyy .          (Dl^-1 alone, what k_schur_lm's product mode reads)
 constexpr int kLmRec = 8;     // lmrec: lx ly ixx ixy iyy ux uy .   (landmark, Dl^-1, u = Dl^-1 g_l)
 
 // 16-byte (f64) / 8-byte (f32) pair loads for the gathered records: one gathered 64-B pose record costs
@@ -104,7 +105,7 @@ template <typename T> __device__ __forceinline__ T block_sum_array(const T* a, i
 //   writes: slot planes a0 a1 ppx ppy (lm-major copy), lmrec[l][2..6] = Dl^-1, u
 template <typename T, int G>
 __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restrict__ ps, T* __restrict__ lmrec,
-                                                   const T* __restrict__ gauge_l) {
+                                                   const T* __restrict__ gauge_l, T* __restrict__ ninv) {
     const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (slice >= tb.n_slices) return;
     const int lane = threadIdx.x & 63;
@@ -139,6 +140,9 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restr
         inv_sym2<T>(dxx + ga, dxy, dyy + ga, ixx, ixy, iyy);
         T* o = lmrec + (size_t)l * kLmRec;
         o[2] = ixx; o[3] = ixy; o[4] = iyy; o[5] = ixx * g0 + ixy * g1; o[6] = ixy * g0 + iyy * g1;
+        // compact copy of Dl^-1 for the Schur product's epilogue: 32 B per landmark instead of a 64-B record
+        T* nq = ninv + (size_t)l * kNinvRec;
+        nq[0] = ixx; nq[1] = ixy; nq[2] = iyy;
     }
 }
 
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __rest
 // HOT KERNEL 1 of the PCG iteration.
 template <typename T, int G, int MODE, int LOW = 0>
 __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __restrict__ zc, T* __restrict__ lmrec,
-                                                     T* __restrict__ t, const CgState<T>* __restrict__ st,
+                                                     const T* __restrict__ ninv, T* __restrict__ t, const CgState<T>* __restrict__ st,
                                                      T step, T* __restrict__ dl_out, T* __restrict__ norm_part) {
     __shared__ T red[kWavesPerBlock];
     if (MODE == 0 && st->done) return;
@@ -305,8 +309,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
         const uint32_t r0 = tb.row_off[slice], r1 = tb.row_off[slice + 1];
         // the inverse block this vertex needs at the very end is requested first: its latency hides behind the rows
         const int lq = (l < tb.n_vertices) ? l : tb.n_vertices - 1;
-        const auto n01 = ld2<T>(lmrec + (size_t)lq * kLmRec + 2);
-        const T n2 = lmrec[(size_t)lq * kLmRec + 4];
+        const auto n01 = ld2<T>(ninv + (size_t)lq * kNinvRec);
+        const T n2 = ninv[(size_t)lq * kNinvRec + 2];
         // UB rows are walked at a time with every load of the batch issued before any use: a wave's time is
         // the depth of its dependent-load chain (row -> index -> gathered pose record), so memory-level
         // parallelism is what buys time.  Rows past the end are clamped (in bounds) and masked out of the sums.

@@ -170,7 +170,7 @@ def main():
                          "us_per_pcg_iteration": opt.time_kernel(5, reps=20)[0],
                          "us_multigrid_numeric_setup": opt.time_kernel(6, reps=5)[0] if amg else None},
         }
-        if world == 1 and not ARGS.no_conv:
+        if not shard and not ARGS.no_conv:      # request-parallel ranks run the same kind of graph: rank 0's own run stands for all
             # the second half of BASELINE.json's metric: Gauss-Newton iterations until the reference's plateau rule
             # |chi2_k - chi2_{k-1}| < 1e-3 fires (OptimizerCpu.h:167-171), capped at 50; a fresh run, outside the timed region
             opt.set_graph(g)

@@ -1,0 +1,46 @@
+"""Research soak (GPU): random mid-size graphs, 12 GN iterations under the reference's stop rules, HIP path against
+the CPU twin (tight tolerances on both).  Exercises warm start, lagged hierarchy, matched aggregates on many shapes."""
+import sys, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+import util
+from oracle import oracle
+from toyslam_amd import synth
+from toyslam_amd.graph import GraphArrays
+from toyslam_amd.optimizer import HipOptimizer
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
+oracle.set_threads(16)
+t_end = time.time() + budget
+worst = 0.0; trial = 0; most_cg = 0; fallbacks = 0
+while time.time() < t_end:
+    n = int(rng.integers(300, 30000)); k = int(rng.integers(2, 15)); lc = int(rng.integers(0, max(1, n // 40)))
+    g = synth.make(n, k, loop_closures=lc, seed=int(rng.integers(0, 10 ** 6)))
+    shape = "landmarks"
+    if trial % 7 == 3:      # plain pose graph
+        keep = g.e_type == 0; pose = g.v_type == 0
+        g = GraphArrays(g.v_id[pose], g.v_type[pose], g.v_pos[pose], g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep], g.fixed)
+        shape = "pose graph"
+    fx = [0] + [int(v) for v in rng.choice(g.v_id, size=int(rng.integers(0, 3)), replace=False)]
+    g.fixed = np.array(fx, np.uint32)
+    o = HipOptimizer(pcg_rel_tol=1e-11)
+    try:
+        o.set_graph(g); r = o.optimize(12); v = o.vertices()
+    finally:
+        o.close()
+    ref = oracle.sparse_optimize(util.to_oracle(g), 12, pcg_tol=1e-12, precond="amg")
+    d = util.max_vertex_diff(v, ref["v_pos"], g.v_type)
+    # the bar is 1e-6 on poses for steps of ordinary size; a diverging run (plain pose graphs with the reference's
+    # -I / +I Jacobians take steps of 1e5 and stop on "worse") is compared relative to its step
+    bar = 1e-6 * max(1.0, r["delta_norm"] / 1e4)
+    diverging = ref["stop"] == "worse"
+    ok = r["iters"] == ref["iters"] and r["stop"] == ref["stop"] and np.allclose(r["chi2"], ref["chi2"], rtol=1e-6 if diverging else 1e-8) \
+        and d < (bar * 10 if diverging else bar)
+    worst = max(worst, d); most_cg = max(most_cg, int(max(r["cg_iters"]))); fallbacks += int(r["fallbacks"])
+    print("trial %3d %-10s n=%6d k=%2d closures=%4d fixed=%d: GN %d/%d stop %s/%s  cg %s  max vertex diff %.2e  %s"
+          % (trial, shape, n, k, lc, len(fx), r["iters"], ref["iters"], r["stop"], ref["stop"], list(map(int, r["cg_iters"])), d, "ok" if ok else "MISMATCH"), flush=True)
+    if not ok:
+        sys.exit(1)
+    trial += 1
+print("soak: %d graphs, worst vertex difference %.2e, most PCG iterations in a solve %d, fallbacks %d" % (trial, worst, most_cg, fallbacks))

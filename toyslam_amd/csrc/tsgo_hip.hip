@@ -188,9 +188,12 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
 
+    double ms_in_malloc = 0; int n_malloc = 0;
     template <typename U> int dalloc(U** out, size_t n) {
         void* ptr = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         HIP_OK(hipMalloc(&ptr, std::max<size_t>(n, 1) * sizeof(U)));
+        ms_in_malloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++n_malloc;
         allocs.push_back(ptr);
         *out = (U*)ptr;
         return 0;
@@ -391,6 +394,7 @@ template <typename T> struct Engine : IEngine {
         predicted_cg = 0;
         if (cfg.use_graphs && pr.world == 1) { if (int rc = capture_cg_graph()) return rc; }
         lap("hipGraph capture");
+        if (say) std::fprintf(stderr, "[tsgo] set_graph: %d hipMalloc calls took %.1f ms in total\n", n_malloc, ms_in_malloc);
         ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return 0;
     }

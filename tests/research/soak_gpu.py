@@ -10,12 +10,13 @@ from toyslam_amd.graph import GraphArrays
 from toyslam_amd.optimizer import HipOptimizer
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+n_lo, n_hi = (int(sys.argv[3]), int(sys.argv[4])) if len(sys.argv) > 4 else (300, 30000)
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 7)
 oracle.set_threads(16)
 t_end = time.time() + budget
 worst = 0.0; trial = 0; most_cg = 0; fallbacks = 0
 while time.time() < t_end:
-    n = int(rng.integers(300, 30000)); k = int(rng.integers(2, 15)); lc = int(rng.integers(0, max(1, n // 40)))
+    n = int(rng.integers(n_lo, n_hi)); k = int(rng.integers(2, 15)); lc = int(rng.integers(0, max(1, n // 40)))
     g = synth.make(n, k, loop_closures=lc, seed=int(rng.integers(0, 10 ** 6)))
     shape = "landmarks"
     if trial % 7 == 3:      # plain pose graph

@@ -125,6 +125,29 @@ def test_c2_10k_poses_against_sparse_cpu_twin(precond):
         assert r["cg_iters"].max() < 120, r["cg_iters"]                       # block-Jacobi needs ~2 800 here
 
 
+def test_warm_start_and_lagged_hierarchy_change_the_work_not_the_answer(monkeypatch):
+    """PCG warm start (x0 = 0.8 * previous delta) and the lagged multigrid hierarchy are accelerations: same chi^2
+    trajectory and vertices as cold starts on a hierarchy rebuilt at every linearisation, in fewer PCG iterations."""
+    g = synth.make_config("c2_10k", seed=5)
+    runs = {}
+    for name, warm, max_age in (("default", 1, None), ("cold_fresh", 0, "1")):
+        if max_age is None:
+            monkeypatch.delenv("TSGO_HIER_MAX_AGE", raising=False)
+        else:
+            monkeypatch.setenv("TSGO_HIER_MAX_AGE", max_age)
+        o = HipOptimizer(pcg_rel_tol=1e-12, warm_start=warm)
+        try:
+            o.set_graph(g); r = o.optimize(10); runs[name] = (r, o.vertices())
+        finally:
+            o.close()
+    (ra, va), (rb, vb) = runs["default"], runs["cold_fresh"]
+    assert ra["iters"] == rb["iters"] == 10 and ra["fallbacks"] == rb["fallbacks"] == 0
+    np.testing.assert_allclose(ra["chi2"], rb["chi2"], rtol=1e-9)
+    assert util.max_vertex_diff(va, vb, g.v_type) < 1e-8
+    assert ra["cg_iters"][0] == rb["cg_iters"][0]                     # the first solve has nothing to start from
+    assert ra["cg_iters"][1:].sum() < rb["cg_iters"][1:].sum() + 3 * 9   # lag costs a few iterations, warm start saves more or about as many
+
+
 def test_bench_tolerance_meets_the_north_star_bar():
     """bench.py runs PCG at rel tol 1e-10 (1e-8 leaves 1.5e-6 on config-2 poses): final chi^2 (relative) and poses (absolute) stay within 1e-6 of
     the dense cpu/eigen restatement on config 1 and of the tightly converged twin on config 2."""

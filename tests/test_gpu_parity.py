@@ -148,6 +148,24 @@ def test_warm_start_and_lagged_hierarchy_change_the_work_not_the_answer(monkeypa
     assert ra["cg_iters"][1:].sum() < rb["cg_iters"][1:].sum() + 3 * 9   # lag costs a few iterations, warm start saves more or about as many
 
 
+def test_collective_path_over_rccl_with_a_single_rank_communicator():
+    """The edge-sharded path (eager launches, block-Jacobi PCG, ncclAllReduce of the pose partials per GN iteration
+    and of the Schur product per PCG iteration) on the one GPU this box has: a world-size-1 RCCL communicator makes
+    the engine take it.  Same answer as the dense reference path; the 2-shard arithmetic is covered on CPU by
+    tests/test_sharded_gloo.py."""
+    g = util.c1_arrays()
+    ref = oracle.optimize(util.to_oracle(g), 6, mode="cpp", solver="chol")
+    o = HipOptimizer(pcg_rel_tol=1e-12, rank=0, world=1)
+    try:
+        o.comm_init(o.comm_unique_id())
+        o.set_graph(g); r = o.optimize(6); v = o.vertices()
+    finally:
+        o.close()
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-10)
+    assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-9
+    assert r["cg_iters"].min() > 30        # block-Jacobi counts: the collective path, not the multigrid one
+
+
 def test_bench_tolerance_meets_the_north_star_bar():
     """bench.py runs PCG at rel tol 1e-10 (1e-8 leaves 1.5e-6 on config-2 poses): final chi^2 (relative) and poses (absolute) stay within 1e-6 of
     the dense cpu/eigen restatement on config 1 and of the tightly converged twin on config 2."""

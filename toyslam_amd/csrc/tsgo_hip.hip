@@ -336,7 +336,7 @@ template <typename T> struct Engine : IEngine {
         lap("layout (build_problem)");
         const int P = pr.P, L = pr.L;
         if (P == 0) return set_error(-2, "tsgo_set_graph: the graph has no Se2 vertex");
-        amg_on = cfg.preconditioner == 1 && pr.world == 1 && pr.P > kCoarsestMax;
+        amg_on = cfg.preconditioner == 1 && !collective() && pr.P > kCoarsestMax;
         if (amg_on) start_amg_builder();
         struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{amg_builder};   // on every error path too
         // state
@@ -392,7 +392,7 @@ template <typename T> struct Engine : IEngine {
         lap("multigrid patterns + upload");
         have_graph_data = true;
         predicted_cg = 0;
-        if (cfg.use_graphs && pr.world == 1) { if (int rc = capture_cg_graph()) return rc; }
+        if (cfg.use_graphs && !collective()) { if (int rc = capture_cg_graph()) return rc; }
         lap("hipGraph capture");
         if (say) std::fprintf(stderr, "[tsgo] set_graph: %d hipMalloc calls took %.1f ms in total\n", n_malloc, ms_in_malloc);
         ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
@@ -573,8 +573,12 @@ template <typename T> struct Engine : IEngine {
         hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[slot], nbC,
                            gpart[slot ^ 1], st[slot], st[slot ^ 1], minv, r, p, q, x, zc, tol2, cfg.pcg_max_iters, (const T*)gscale_dev);
     }
+    // The collective path (eager launches, block-Jacobi PCG, all-reduces between kernels) is taken by every shard of a
+    // split graph — and by a single shard that was given a communicator (tsgo_comm_init with world = 1), which is how
+    // the RCCL plumbing is exercised on a one-GPU box.
+    bool collective() const { return pr.world > 1 || comm != nullptr; }
     int allreduce(T* buf, size_t n) {
-        if (pr.world <= 1) return 0;
+        if (!collective()) return 0;
         if (!comm) return set_error(-12, "world > 1 but tsgo_comm_init was not called");
         NCCL_OK(ncclAllReduce(buf, buf, n, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream));
         return 0;
@@ -706,7 +710,7 @@ template <typename T> struct Engine : IEngine {
         double np2 = 0, nl2 = 0;
         for (int k = 0; k < nbC; ++k) np2 += (double)h_scratch[k];
         for (int k = 0; k < nl; ++k) nl2 += (double)h_scratch[nbC + k];
-        if (pr.world > 1) {      // landmark deltas are shard-local
+        if (collective()) {      // landmark deltas are shard-local
             T* d = part;          // reuse as a one-element device scratch
             T v = (T)nl2;
             HIP_OK(hipMemcpyAsync(d, &v, sizeof(T), hipMemcpyHostToDevice, stream));

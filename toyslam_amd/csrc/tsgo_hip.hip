@@ -669,7 +669,13 @@ template <typename T> struct Engine : IEngine {
     int do_solve_once(int* iters, int* fail) {
         int launched = 0;
         const int ch = chunk();
-        int burst = std::max(1, (int)(0.9 * predicted_cg) / ch);    // chunks before the first look
+        // chunks before the first look at the device state.  An iteration past convergence costs ~40 us (its kernels exit
+        // at once), a look costs about as much plus an idle gap: under the multigrid cycle, where counts move by one or
+        // two between solves, the burst aims one iteration past the prediction (a solve on a fresh hierarchy is predicted
+        // by the last fresh one, an aged one by the previous solve + 1); block-Jacobi counts are in the thousands and
+        // drift, so that burst stops at 90 %.
+        const int pred = amg_on ? (hier_age == 0 && iters_fresh > 0 ? iters_fresh : predicted_cg + 1) : predicted_cg;
+        int burst = amg_on ? std::max(1, (pred + 1 + ch - 1) / ch) : std::max(1, (int)(0.9 * pred) / ch);
         static const bool timing = getenv("TSGO_SOLVE_TIMING") != nullptr;
         const auto w0 = std::chrono::steady_clock::now();
         auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count(); };

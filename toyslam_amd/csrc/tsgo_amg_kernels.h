@@ -272,7 +272,8 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
                                                           const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
     if (MODE != 2 && st->done) return;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
-    const int i = g < n ? g : n - 1;
+    // LPR == 64: the row is wave-uniform, its bounds come through the scalar cache (one dependent round trip shorter)
+    const int i = LPR == 64 ? __builtin_amdgcn_readfirstlane(g < n ? g : n - 1) : (g < n ? g : n - 1);
     T s0 = 0, s1 = 0, s2 = 0;
     for (int a = ptr[i] + sub; a < ptr[i + 1]; a += LPR) {
         const HT<T>* b = A + (size_t)a * 9; const T* v = z + (size_t)col[a] * 3;

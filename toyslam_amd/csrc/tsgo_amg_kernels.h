@@ -22,6 +22,7 @@ template <typename T> struct Hier { using type = float; };
 #endif
 template <typename T> using HT = typename Hier<T>::type;
 
+constexpr int kPairBlocksPerWave = 21;   // k_pair_gemm: three lanes per 3x3 output block
 constexpr int kDenseMax = 84;            // coarsest matrix is at most 84 x 84 (host/amg.h: kCoarsestMax * 3)
 
 template <typename T, typename A, typename B> __device__ __forceinline__ void m3_mul_acc(const A* a, const B* b, T* c) {
@@ -150,9 +151,9 @@ __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __r
         for (int j = 0; j < 3; ++j) rt[3 * i + j] = o[3 * j + i];
 }
 
-// out[o] = sum over its pair list of X[x] * Y[y]  (TRANS: X[x]^T * Y[y]).  Nine lanes per output block,
-// one per element: a lane reads one row of X and one column of Y per pair (the nine lanes of a block
-// touch the same two 72-byte blocks, so the loads coalesce), 7 output blocks per wavefront.
+// out[o] = sum over its pair list of X[x] * Y[y]  (TRANS: X[x]^T * Y[y]).  Three lanes per output block, one per
+// output row: per pair a lane reads one row (column when TRANS) of X and the whole 36-byte Y block — 14 loads for
+// 9 multiply-adds, against 8 loads for 3 with a lane per element — and 21 output blocks share a wavefront.
 template <typename T, int TRANS>
 __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __restrict__ ptr, const int* __restrict__ px,
                                                       const int* __restrict__ py, const HT<T>* __restrict__ X, const HT<T>* __restrict__ Y,
@@ -160,31 +161,36 @@ __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __re
     const int lane = threadIdx.x & 63;
     if (lane >= 63) return;
     const int wave = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    const int oo = wave * 7 + lane / 9, e = lane % 9, i = e / 3, j = e % 3;
+    const int oo = wave * kPairBlocksPerWave + lane / 3, i = lane % 3;
     if (oo >= n_out) return;
     const int o = which ? which[oo] : oo;        // which: the output blocks that have a pair list (the others are mirrored)
-    T acc = 0;
-    // the list is walked four pairs at a time with every index load, then every value load, issued before the
-    // arithmetic: a lane's time is its chain of dependent loads (index -> block), not bandwidth
-    constexpr int U = 4;
+    T acc0 = 0, acc1 = 0, acc2 = 0;
+    // two pairs per trip, index loads first, then value loads, then arithmetic
+    constexpr int U = 2;
     const int qe = ptr[o + 1];
     for (int q = ptr[o]; q < qe; q += U) {
         int xi[U], yi[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) { const int qq = q + u < qe ? q + u : qe - 1; xi[u] = px[qq]; yi[u] = py[qq]; }
-        HT<T> a[U][3], b[U][3];
+        HT<T> a[U][3], b[U][9];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const HT<T>* pa = X + (size_t)xi[u] * 9; const HT<T>* pb = Y + (size_t)yi[u] * 9;
             if (TRANS) { a[u][0] = pa[i]; a[u][1] = pa[3 + i]; a[u][2] = pa[6 + i]; }
             else { a[u][0] = pa[3 * i]; a[u][1] = pa[3 * i + 1]; a[u][2] = pa[3 * i + 2]; }
-            b[u][0] = pb[j]; b[u][1] = pb[3 + j]; b[u][2] = pb[6 + j];
+#pragma unroll
+            for (int m = 0; m < 9; ++m) b[u][m] = pb[m];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
-            if (q + u < qe) acc += T(a[u][0]) * T(b[u][0]) + T(a[u][1]) * T(b[u][1]) + T(a[u][2]) * T(b[u][2]);
+            if (q + u < qe) {
+                acc0 += T(a[u][0]) * T(b[u][0]) + T(a[u][1]) * T(b[u][3]) + T(a[u][2]) * T(b[u][6]);
+                acc1 += T(a[u][0]) * T(b[u][1]) + T(a[u][1]) * T(b[u][4]) + T(a[u][2]) * T(b[u][7]);
+                acc2 += T(a[u][0]) * T(b[u][2]) + T(a[u][1]) * T(b[u][5]) + T(a[u][2]) * T(b[u][8]);
+            }
     }
-    out[(size_t)o * 9 + e] = acc;
+    HT<T>* po = out + (size_t)o * 9 + 3 * i;
+    po[0] = acc0; po[1] = acc1; po[2] = acc2;
 }
 
 // Same product for levels whose pair lists are long (smoothed Galerkin matrices get dense: hundreds of pairs

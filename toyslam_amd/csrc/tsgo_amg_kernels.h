@@ -196,24 +196,26 @@ __global__ __launch_bounds__(kBlock) void k_pair_gemm(int n_out, const int* __re
 // Same product for levels whose pair lists are long (smoothed Galerkin matrices get dense: hundreds of pairs
 // per output block): one wavefront per output block, lanes stride over the pairs and keep nine partial
 // sums each, xor-shuffle reduction at the end.  The nine-lane kernel above would walk such a list serially.
-template <typename T, int TRANS>
+template <typename T, int TRANS, int LPB = 64>
 __global__ __launch_bounds__(kBlock) void k_pair_gemm_wave(int n_out, const int* __restrict__ ptr, const int* __restrict__ px,
                                                            const int* __restrict__ py, const HT<T>* __restrict__ X, const HT<T>* __restrict__ Y,
                                                            HT<T>* __restrict__ out, const int* __restrict__ which) {
-    const int lane = threadIdx.x & 63;
-    const int oo = (blockIdx.x * kBlock + threadIdx.x) >> 6;
-    if (oo >= n_out) return;
-    const int o = which ? which[oo] : oo;
+    // LPB lanes (64 or 16) share one output block
+    const int sub = threadIdx.x % LPB;
+    const int oo = (blockIdx.x * kBlock + threadIdx.x) / LPB;
+    const bool live = oo < n_out;
+    const int o = live ? (which ? which[oo] : oo) : 0;
     T acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-    for (int q = ptr[o] + lane; q < ptr[o + 1]; q += 64) {
-        T a[9], b[9];
+    if (live)
+        for (int q = ptr[o] + sub; q < ptr[o + 1]; q += LPB) {
+            T a[9], b[9];
 #pragma unroll
-        for (int m = 0; m < 9; ++m) { a[m] = X[(size_t)px[q] * 9 + m]; b[m] = Y[(size_t)py[q] * 9 + m]; }
-        if (TRANS) m3_tmul_acc<T>(a, b, acc); else m3_mul_acc<T>(a, b, acc);
-    }
+            for (int m = 0; m < 9; ++m) { a[m] = X[(size_t)px[q] * 9 + m]; b[m] = Y[(size_t)py[q] * 9 + m]; }
+            if (TRANS) m3_tmul_acc<T>(a, b, acc); else m3_mul_acc<T>(a, b, acc);
+        }
 #pragma unroll
-    for (int m = 0; m < 9; ++m) acc[m] = wave_sum<T>(acc[m]);
-    if (lane == 0) {
+    for (int m = 0; m < 9; ++m) acc[m] = group_sum<T, LPB>(acc[m]);
+    if (live && sub == 0) {
 #pragma unroll
         for (int m = 0; m < 9; ++m) out[(size_t)o * 9 + m] = acc[m];
     }

@@ -94,7 +94,9 @@ struct IEngine {
 constexpr int kRhoSteps = 16, kRhoBlocks = 64, kRhoEvery = 8;   // smoother-damping estimate: power steps, partial sums, refresh period
 constexpr int kAmgIterCap = 400;        // a multigrid-preconditioned solve that needs more than this is treated as a
                                         // failed preconditioner (stagnation) and repeated with block-Jacobi
-constexpr double kLongPairList = 24;    // Galerkin products with longer average lists use one wavefront per output block
+constexpr double kMediumPairList = 6;   // Galerkin products whose average pair list is longer than this share an output block among 8 lanes,
+constexpr double kLongPairList = 16;    // ... longer than this among 16 lanes ...
+constexpr double kVeryLongPairList = 200; // ... or a whole wavefront
 constexpr double kCertifySlack = 1e4;   // certificate: sqrt(r^T D^-1 r / b^T D^-1 b) <= slack * tol (norms differ by up to ~sqrt(cond))
 constexpr int kHierMaxAge = 4;          // a multigrid hierarchy serves at most this many consecutive linearisations ...
 constexpr int kHierSlack = 2;           // ... and is rebuilt as soon as a solve needs more than this many iterations over its first
@@ -389,6 +391,9 @@ template <typename T> struct Engine : IEngine {
         if (amg_on) { if (int rc = upload_amg()) return rc; }
         HIP_OK(hipDeviceSynchronize());
         if (say) std::fprintf(stderr, "[tsgo] set_graph:   of which multigrid patterns on the host %8.1f ms\n", ms_amg_symbolic);
+        if (say) for (size_t l = 0; l < lv.size(); ++l)
+            std::fprintf(stderr, "[tsgo] level %zu: %d rows, %d blocks; pairs per block: A*P %.1f (%d blocks), P^T(AP) %.1f (%d upper blocks)\n", l, lv[l].n, lv[l].nnzA,
+                         lv[l].pairs_T, lv[l].nnzT, lv[l].pairs_A, lv[l].n_upper);
         lap("multigrid patterns + upload");
         have_graph_data = true;
         predicted_cg = 0;
@@ -433,9 +438,13 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL((k_block_inv<T>), dim3(grid_for(L.n)), dim3(kBlock), 0, stream, L.n, L.diag, (const H*)L.A, L.Dinv);
             hipLaunchKernelGGL((k_prolongator<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, L.P_row, L.p_self, L.ps_ptr, L.ps_x, L.ps_y,
                                (const H*)L.A, (const H*)L.Dinv, (const T*)L.rel, (T)kProlongOmega, L.P, L.p_to_r, L.Rv);
-            if (L.pairs_T > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 0>), dim3(grid_for(L.nnzT, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv, (const int*)nullptr);
+            if (L.pairs_T > kVeryLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 0, 64>), dim3(grid_for(L.nnzT, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv, (const int*)nullptr);
+            else if (L.pairs_T > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 0, 16>), dim3(grid_for(L.nnzT, 16)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv, (const int*)nullptr);
+            else if (L.pairs_T > kMediumPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 0, 8>), dim3(grid_for(L.nnzT, 8)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv, (const int*)nullptr);
             else hipLaunchKernelGGL((k_pair_gemm<T, 0>), dim3(grid_for((L.nnzT + kPairBlocksPerWave - 1) / kPairBlocksPerWave, 64)), dim3(kBlock), 0, stream, L.nnzT, L.ts_ptr, L.ts_x, L.ts_y, (const H*)L.A, (const H*)L.P, L.Tv, (const int*)nullptr);
-            if (L.pairs_A > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1>), dim3(grid_for(L.n_upper, 64)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
+            if (L.pairs_A > kVeryLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1, 64>), dim3(grid_for(L.n_upper, 64)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
+            else if (L.pairs_A > kLongPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1, 16>), dim3(grid_for(L.n_upper, 16)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
+            else if (L.pairs_A > kMediumPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1, 8>), dim3(grid_for(L.n_upper, 8)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
             else hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.n_upper + kPairBlocksPerWave - 1) / kPairBlocksPerWave, 64)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
             hipLaunchKernelGGL((k_mirror_blocks<T>), dim3(grid_for(L.nnzNext, 9)), dim3(kBlock), 0, stream, L.nnzNext, (const int*)L.as_mirror, Anext);
         }

@@ -98,7 +98,7 @@ constexpr double kMediumPairList = 6;   // Galerkin products whose average pair 
 constexpr double kLongPairList = 16;    // ... longer than this among 16 lanes ...
 constexpr double kVeryLongPairList = 200; // ... or a whole wavefront
 constexpr double kCertifySlack = 1e4;   // certificate: sqrt(r^T D^-1 r / b^T D^-1 b) <= slack * tol (norms differ by up to ~sqrt(cond))
-constexpr int kHierMaxAge = 4;          // a multigrid hierarchy serves at most this many consecutive linearisations ...
+constexpr int kHierMaxAge = 2;          // a multigrid hierarchy serves at most this many consecutive linearisations ...
 constexpr int kHierSlack = 2;           // ... and is rebuilt as soon as a solve needs more than this many iterations over its first
 constexpr int kChunk = 16;   // PCG iterations per captured hipGraph (even: the state ring has 2 slots)
 constexpr int kChunkAmg = 2; // with the multigrid V-cycle an iteration is ~30 launches and a solve ~50 iterations

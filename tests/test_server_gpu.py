@@ -104,3 +104,36 @@ def test_client_class_and_malformed_request(server):
     c.connect()
     assert len(c.optimize(g).v_id) == len(g.v_id)
     c.close()
+
+
+def test_requests_from_several_connections_run_concurrently_and_stay_correct(server):
+    """Three clients at once (the server keeps up to ENGINES = 2 requests in flight on the device, each on its own
+    engine handle and stream): every reply must be the answer to ITS request."""
+    import threading
+    from toyslam_amd import synth
+    port, proc = server
+    graphs = [synth.make(1500 + 400 * k, 6 + k, loop_closures=5, seed=40 + k) for k in range(3)]
+    refs = [oracle.sparse_optimize(util.to_oracle(g.rounded_to_wire()), 50, pcg_tol=1e-12, precond="amg") for g in graphs]
+    outs = [None] * 3
+    errs = []
+
+    def client(k):
+        try:
+            c = remote.GraphClient("127.0.0.1", port)
+            c.connect()
+            for _ in range(2):                      # two requests per connection, interleaving with the others
+                outs[k] = c.optimize(graphs[k])
+            c.close()
+        except Exception as e:                      # noqa: BLE001 - reported below
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=client, args=(k,)) for k in range(3)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=120)
+    assert not errs, errs
+    assert proc.poll() is None
+    for k in range(3):
+        assert outs[k] is not None and len(outs[k].v_id) == len(graphs[k].v_id)
+        assert util.max_vertex_diff(outs[k].v_pos, refs[k]["v_pos"], graphs[k].v_type) < 2e-4    # f32 on the wire

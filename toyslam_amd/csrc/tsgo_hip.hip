@@ -191,6 +191,15 @@ template <typename T> struct Engine : IEngine {
     }
 
     double ms_in_malloc = 0; int n_malloc = 0;
+    // Every copy and fill goes through THIS engine's stream (never the legacy default stream): several engines serve
+    // requests from different threads of one process, and a legacy-stream call in one thread is refused by the runtime
+    // while another thread captures a graph.
+    int copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
+        HIP_OK(hipMemcpyAsync(dst, src, bytes, kind, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        return 0;
+    }
+    int fill_zero(void* dst, size_t bytes) { HIP_OK(hipMemsetAsync(dst, 0, bytes, stream)); return 0; }
     template <typename U> int dalloc(U** out, size_t n) {
         void* ptr = nullptr;
         const auto t0 = std::chrono::steady_clock::now();
@@ -205,24 +214,24 @@ template <typename T> struct Engine : IEngine {
         if (n == 0) return 0;
         std::vector<T> tmp(n);
         for (size_t k = 0; k < n; ++k) tmp[k] = (T)src[k];
-        HIP_OK(hipMemcpy(*out, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice));
+        { if (int rc_ = copy_sync(*out, tmp.data(), n * sizeof(T), hipMemcpyHostToDevice)) return rc_; }
         return 0;
     }
     int upload_u32(const uint32_t** out, const std::vector<uint32_t>& v) {
         uint32_t* d = nullptr;
         if (int rc = dalloc(&d, v.size())) return rc;
-        if (!v.empty()) HIP_OK(hipMemcpy(d, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!v.empty()) { if (int rc_ = copy_sync(d, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) return rc_; }
         *out = d;
         return 0;
     }
     int upload_i32(int** out, const std::vector<int>& v) {
         if (int rc = dalloc(out, v.size())) return rc;
-        if (!v.empty()) HIP_OK(hipMemcpy(*out, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice));
+        if (!v.empty()) { if (int rc_ = copy_sync(*out, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice)) return rc_; }
         return 0;
     }
     int upload_u32m(uint32_t** out, const std::vector<uint32_t>& v) {
         if (int rc = dalloc(out, v.size())) return rc;
-        if (!v.empty()) HIP_OK(hipMemcpy(*out, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+        if (!v.empty()) { if (int rc_ = copy_sync(*out, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) return rc_; }
         return 0;
     }
     static std::vector<int> rows_of(const BlockCsr& m) {
@@ -290,7 +299,7 @@ template <typename T> struct Engine : IEngine {
         if (lv.size() > 16) return set_error(-2, "tsgo_set_graph: too many multigrid levels");
         {
             std::vector<T> init(16, (T)kSmootherOmega); init[0] = (T)kSmoother0Omega;
-            HIP_OK(hipMemcpy(omega_dev, init.data(), 16 * sizeof(T), hipMemcpyHostToDevice));
+            { if (int rc_ = copy_sync(omega_dev, init.data(), 16 * sizeof(T), hipMemcpyHostToDevice)) return rc_; }
             omega_host.assign(lv.size(), kSmootherOmega); omega_host[0] = kSmoother0Omega;
         }
         if (h_rho) (void)hipHostFree(h_rho);
@@ -317,8 +326,8 @@ template <typename T> struct Engine : IEngine {
         t.st = stp;
         if (int rc = dalloc(&t.dyn, (size_t)dyn_planes * h.slots())) return rc;
         t.dyn32 = nullptr;
-        if (pairs) { if (int rc = dalloc(&t.dyn32, h.slots())) return rc; HIP_OK(hipMemset(t.dyn32, 0, std::max<size_t>(h.slots(), 1) * sizeof(float4))); }
-        HIP_OK(hipMemset(t.dyn, 0, std::max<size_t>((size_t)dyn_planes * h.slots(), 1) * sizeof(T)));
+        if (pairs) { if (int rc = dalloc(&t.dyn32, h.slots())) return rc; { if (int rc_ = fill_zero(t.dyn32, std::max<size_t>(h.slots(), 1) * sizeof(float4))) return rc_; } }
+        { if (int rc_ = fill_zero(t.dyn, std::max<size_t>((size_t)dyn_planes * h.slots(), 1) * sizeof(T))) return rc_; }
         return 0;
     }
 
@@ -370,26 +379,26 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&q, (size_t)P * 3)) return rc;
         if (int rc = dalloc(&x, (size_t)P * 3)) return rc;
         if (int rc = dalloc(&zc, (size_t)P * kPoseRec)) return rc;
-        HIP_OK(hipMemset(zc, 0, (size_t)P * kPoseRec * sizeof(T)));
+        { if (int rc_ = fill_zero(zc, (size_t)P * kPoseRec * sizeof(T))) return rc_; }
         if (int rc = dalloc(&sbuf, (size_t)P * 3 + nbP)) return rc;
         if (int rc = dalloc(&tvec, (size_t)std::max(L, 1) * 2)) return rc;
         if (int rc = dalloc(&ninv, (size_t)std::max(L, 1) * kNinvRec)) return rc;
-        HIP_OK(hipMemset(ninv, 0, (size_t)std::max(L, 1) * kNinvRec * sizeof(T)));
+        { if (int rc_ = fill_zero(ninv, (size_t)std::max(L, 1) * kNinvRec * sizeof(T))) return rc_; }
         if (int rc = dalloc(&dl, (size_t)std::max(L, 1) * 2)) return rc;
-        HIP_OK(hipMemset(dl, 0, (size_t)std::max(L, 1) * 2 * sizeof(T)));
+        { if (int rc_ = fill_zero(dl, (size_t)std::max(L, 1) * 2 * sizeof(T))) return rc_; }
         for (int k = 0; k < 2; ++k) { if (int rc = dalloc(&gpart[k], nbC)) return rc; if (int rc = dalloc(&st[k], 1)) return rc; }
         if (int rc = dalloc(&npart, (size_t)nbC + std::max(nbL, 1))) return rc;
         if (int rc = dalloc(&one_dev, 1)) return rc;
         if (int rc = dalloc(&gscale_dev, 1)) return rc;
         if (int rc = dalloc(&xprev, (size_t)P * 3)) return rc;
         have_prev = false;
-        { const T one = 1; HIP_OK(hipMemcpy(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)); HIP_OK(hipMemcpy(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)); }
+        { const T one = 1; { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; } { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; } }
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
-        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipStreamSynchronize(stream));
         lap("state + slot tables to the device");
         if (amg_on) { if (int rc = upload_amg()) return rc; }
-        HIP_OK(hipDeviceSynchronize());
+        HIP_OK(hipStreamSynchronize(stream));
         if (say) std::fprintf(stderr, "[tsgo] set_graph:   of which multigrid patterns on the host %8.1f ms\n", ms_amg_symbolic);
         if (say) for (size_t l = 0; l < lv.size(); ++l)
             std::fprintf(stderr, "[tsgo] level %zu: %d rows, %d blocks; pairs per block: A*P %.1f (%d blocks), P^T(AP) %.1f (%d upper blocks)\n", l, lv[l].n, lv[l].nnzA,
@@ -787,8 +796,8 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipSetDevice(cfg.device));
         const int P = pr.P, L = pr.L;
         std::vector<T> hp((size_t)P * 4), hl((size_t)std::max(L, 1) * kLmRec);
-        HIP_OK(hipMemcpy(hp.data(), ps, hp.size() * sizeof(T), hipMemcpyDeviceToHost));
-        if (L) HIP_OK(hipMemcpy(hl.data(), lmrec, (size_t)L * kLmRec * sizeof(T), hipMemcpyDeviceToHost));
+        { if (int rc_ = copy_sync(hp.data(), ps, hp.size() * sizeof(T), hipMemcpyDeviceToHost)) return rc_; }
+        if (L) { if (int rc_ = copy_sync(hl.data(), lmrec, (size_t)L * kLmRec * sizeof(T), hipMemcpyDeviceToHost)) return rc_; }
         for (int i = 0; i < P; ++i) {
             const int v = pr.pose_vertex[i];
             out[3 * (size_t)v] = hp[4 * (size_t)i]; out[3 * (size_t)v + 1] = hp[4 * (size_t)i + 1];
@@ -807,8 +816,8 @@ template <typename T> struct Engine : IEngine {
         if (int rc = do_linearize(chi2)) return rc;
         const int P = pr.P, L = pr.L;
         std::vector<T> hpart((size_t)P * 18), hl((size_t)std::max(L, 1) * kLmRec);
-        HIP_OK(hipMemcpy(hpart.data(), part, hpart.size() * sizeof(T), hipMemcpyDeviceToHost));
-        if (L) HIP_OK(hipMemcpy(hl.data(), lmrec, (size_t)L * kLmRec * sizeof(T), hipMemcpyDeviceToHost));
+        { if (int rc_ = copy_sync(hpart.data(), part, hpart.size() * sizeof(T), hipMemcpyDeviceToHost)) return rc_; }
+        if (L) { if (int rc_ = copy_sync(hl.data(), lmrec, (size_t)L * kLmRec * sizeof(T), hipMemcpyDeviceToHost)) return rc_; }
         std::memset(diag, 0, sizeof(double) * 9 * (size_t)pr.n_vertices);
         std::memset(grad, 0, sizeof(double) * 3 * (size_t)pr.n_vertices);
         for (int i = 0; i < P; ++i) {
@@ -840,8 +849,8 @@ template <typename T> struct Engine : IEngine {
         if (int rc = do_backsub_update((T)0, &nrm)) return rc;
         const int P = pr.P, L = pr.L;
         std::vector<T> hx((size_t)P * 3), hd((size_t)std::max(L, 1) * 2);
-        HIP_OK(hipMemcpy(hx.data(), x, hx.size() * sizeof(T), hipMemcpyDeviceToHost));
-        if (L) HIP_OK(hipMemcpy(hd.data(), dl, (size_t)L * 2 * sizeof(T), hipMemcpyDeviceToHost));
+        { if (int rc_ = copy_sync(hx.data(), x, hx.size() * sizeof(T), hipMemcpyDeviceToHost)) return rc_; }
+        if (L) { if (int rc_ = copy_sync(hd.data(), dl, (size_t)L * 2 * sizeof(T), hipMemcpyDeviceToHost)) return rc_; }
         std::memset(delta, 0, sizeof(double) * 3 * (size_t)pr.n_vertices);
         for (int i = 0; i < P; ++i) for (int k = 0; k < 3; ++k) delta[3 * (size_t)pr.pose_vertex[i] + k] = hx[(size_t)i * 3 + k];
         for (int l = 0; l < L; ++l) for (int k = 0; k < 2; ++k) delta[3 * (size_t)pr.lm_vertex[l] + k] = hd[(size_t)l * 2 + k];

@@ -481,6 +481,7 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     auto agg_at = [&](size_t l) { return agg_list[std::min(l, agg_list.size() - 1)]; };
     const int agg0 = agg_at(0);
     const int smooth_levels = getenv("TSGO_SMOOTH_LEVELS") ? atoi(getenv("TSGO_SMOOTH_LEVELS")) : kSmoothLevels;
+    const int smooth_from = getenv("TSGO_SMOOTH_FROM") ? atoi(getenv("TSGO_SMOOTH_FROM")) : 0;     // research: tentative prolongators above this level
     // research override: TSGO_AGG_MODE=traj cuts the trajectory into runs of consecutive poses instead (the first version)
     const bool matching = !(getenv("TSGO_AGG_MODE") && std::string(getenv("TSGO_AGG_MODE")) == "traj");
     WGraph wg; std::vector<int> wkey;
@@ -506,7 +507,7 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     for (;;) {
         if (cur.n <= kCoarsestMax) { S.A_last = cur.A; S.diag_last = find_diag(cur.A); break; }
         BlockCsr A_next; std::vector<double> xy_next;
-        const std::string cerr = coarsen(cur, xy, rigid, A_next, xy_next, (int)S.levels.size() < smooth_levels);
+        const std::string cerr = coarsen(cur, xy, rigid, A_next, xy_next, (int)S.levels.size() < smooth_levels && (int)S.levels.size() >= smooth_from);
         if (!cerr.empty()) return cerr;
         sw.lap("coarsen level");
         const int na = cur.n_agg;

@@ -409,6 +409,23 @@ struct Twin {
         return it;
     }
 
+    // As Engine::do_solve (tsgo_hip.hip): a multigrid-preconditioned solve that breaks down (indefinite or singular
+    // coarse operator, e.g. a graph without any fixed vertex) is repeated from the same right-hand side with block-Jacobi.
+    int n_fallbacks = 0;
+    int solve_with_fallback(double gamma_first, double tol, int max_it, bool* ok) {
+        int it = solve(gamma_first, tol, max_it, ok);
+        if (!*ok && use_amg) {
+            ++n_fallbacks;
+            use_amg = false;
+            const double g0 = finalize();          // r = b~, x = 0, z = D^-1 r
+            gamma_ref = g0;
+            it = solve(g0, tol, max_it, ok);
+            use_amg = true;
+            hier_age = -1;
+        }
+        return it;
+    }
+
     // back-substitution for the landmarks: delta_l = u - Dl^-1 W^T delta_p
     void backsub(std::vector<double>& dl) {
         schur_lm(x);
@@ -476,7 +493,7 @@ int oracle_sparse_step(GRAPH_ARGS, double pcg_tol, int max_cg, int precond, int 
     if (!tw.init(g, rank, world).empty()) return -2;
     if (precond == 1 && !tw.enable_amg().empty()) return -5;
     const double gamma0 = tw.linearize();
-    bool ok; *cg_iters = tw.solve(gamma0, pcg_tol, max_cg, &ok);
+    bool ok; *cg_iters = tw.solve_with_fallback(gamma0, pcg_tol, max_cg, &ok);
     std::vector<double> dl; tw.backsub(dl);
     std::memset(delta_out, 0, sizeof(double) * 3 * (size_t)nV);
     tw.store(nullptr, delta_out, &dl);
@@ -508,7 +525,7 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
         const double err = tw.chi2;
         chi2_trace[it] = err; *iters_run = it + 1;
         if (prevErr > 0 && err > prevErr) { if (++penalty > 2) { *stop_reason = 1; break; } } else penalty = 0;
-        bool ok; cg_trace[it] = tw.solve(gamma0, pcg_tol, max_cg, &ok);
+        bool ok; cg_trace[it] = tw.solve_with_fallback(gamma0, pcg_tol, max_cg, &ok);
         if (!ok) { *stop_reason = 4; break; }
         xprev = tw.x;
         std::vector<double> dl; tw.backsub(dl);

@@ -24,3 +24,16 @@ def test_vertex_and_edge_order_do_not_matter():
     b = oracle.sparse_optimize(util.to_oracle(gs), 6, pcg_tol=1e-13, precond="amg")
     np.testing.assert_allclose(a["chi2"], b["chi2"], rtol=1e-10)
     assert util.max_vertex_diff(a["v_pos"][pv], b["v_pos"], gs.v_type) < 1e-9
+
+
+@pytest.mark.parametrize("precond", ["jacobi", "amg"])
+def test_gauge_free_graph_keeps_the_chi2_trajectory_of_the_rank_revealing_qr(precond):
+    """No fixed vertex: H is singular (a rigid motion of everything costs nothing).  The reference's column-pivoted QR
+    returns one of the solutions; PCG on the consistent singular system returns another (a different rigid drift) with
+    the SAME chi^2 trajectory — the quantity that does not depend on the gauge.  The multigrid hierarchy's coarsest
+    matrix is singular there, the solve breaks down and is repeated with block-Jacobi."""
+    g = edge_cases.no_fixed_vertex()
+    ref = oracle.optimize(util.to_oracle(g), 6, mode="cpp", solver="qr")
+    r = oracle.sparse_optimize(util.to_oracle(g), 6, pcg_tol=1e-12, precond=precond)
+    assert r["iters"] == ref["iters"] and r["stop"] == ref["stop"]
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-8)

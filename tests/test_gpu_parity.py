@@ -289,6 +289,21 @@ def test_edge_case_graphs_match_cpu_eigen(opt, name):
     assert util.max_vertex_diff(opt.vertices(), ref["v_pos"], g.v_type) < 1e-8
 
 
+def test_gauge_free_graph_on_the_device():
+    """No fixed vertex (singular H): same chi^2 trajectory as the reference's rank-revealing QR; every multigrid solve
+    breaks down on the singular coarsest matrix and is repeated with block-Jacobi (counted in pcg_fallbacks)."""
+    g = edge_cases.no_fixed_vertex()
+    ref = oracle.optimize(util.to_oracle(g), 6, mode="cpp", solver="qr")
+    o = HipOptimizer(pcg_rel_tol=1e-12)
+    try:
+        o.set_graph(g); r = o.optimize(6)
+    finally:
+        o.close()
+    assert r["iters"] == ref["iters"] and r["stop"] == ref["stop"]
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-8)
+    assert r["fallbacks"] >= 1
+
+
 def test_vertex_and_edge_order_do_not_matter_on_the_device(opt):
     g = edge_cases.base()
     gs, pv = edge_cases.shuffled_vertices_and_edges()

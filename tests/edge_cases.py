@@ -75,6 +75,19 @@ def no_fixed_vertex():
     return g
 
 
+def near_optimum(rounds=6):
+    """tiny_a re-started from its own optimised vertices until the first step is shorter than 1e-3: the run then stops
+    on the reference's third rule ("CONVERGED", OptimizerCpu.h:173-177) after one iteration."""
+    from oracle import oracle
+    from tests import util
+    t = util.tiny_arrays("tiny_a")
+    cur = t
+    for _ in range(rounds):
+        r = oracle.optimize(util.to_oracle(cur), 400, mode="cpp", solver="chol")
+        cur = GraphArrays(t.v_id, t.v_type, r["v_pos"].copy(), t.e_type, t.e_ids, t.e_meas, t.e_inf, t.fixed)
+    return cur
+
+
 CASES = {
     "fixed_landmark_dup_fixed": fixed_landmark_and_duplicate_fixed_ids,
     "isolated_vertices": isolated_vertices,

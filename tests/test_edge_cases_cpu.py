@@ -37,3 +37,15 @@ def test_gauge_free_graph_keeps_the_chi2_trajectory_of_the_rank_revealing_qr(pre
     r = oracle.sparse_optimize(util.to_oracle(g), 6, pcg_tol=1e-12, precond=precond)
     assert r["iters"] == ref["iters"] and r["stop"] == ref["stop"]
     np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-8)
+
+
+def test_every_stop_rule_of_the_reference_is_reached():
+    """OptimizerCpu.h:140-153 (error rose three times), :167-171 (plateau), :173-177 (short step), the iteration cap:
+    the dense restatement and the sparse twin stop in the same iteration for the same reason."""
+    cases = {"worse": (edge_cases.pose_graph_without_landmarks(), 50), "plateau": (util.c1_arrays(), 50),
+             "converged": (edge_cases.near_optimum(), 50), "cap": (util.c1_arrays(), 7)}
+    for want, (g, n) in cases.items():
+        ref = oracle.optimize(util.to_oracle(g), n, mode="cpp", solver="chol")
+        r = oracle.sparse_optimize(util.to_oracle(g), n, pcg_tol=1e-13, precond="amg")
+        assert ref["stop"] == want, (want, ref["stop"])
+        assert (r["stop"], r["iters"]) == (ref["stop"], ref["iters"]), (want, r["stop"], r["iters"], ref["iters"])

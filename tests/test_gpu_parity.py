@@ -289,6 +289,22 @@ def test_edge_case_graphs_match_cpu_eigen(opt, name):
     assert util.max_vertex_diff(opt.vertices(), ref["v_pos"], g.v_type) < 1e-8
 
 
+def test_every_stop_rule_of_the_reference_is_reached_on_the_device():
+    """Error rose three times / plateau / short step / iteration cap (OptimizerCpu.h:140-153,167-177): the device stops in
+    the same iteration for the same reason as the dense restatement."""
+    cases = {"worse": (edge_cases.pose_graph_without_landmarks(), 50), "plateau": (util.c1_arrays(), 50),
+             "converged": (edge_cases.near_optimum(), 50), "cap": (util.c1_arrays(), 7)}
+    for want, (g, n) in cases.items():
+        ref = oracle.optimize(util.to_oracle(g), n, mode="cpp", solver="chol")
+        o = HipOptimizer(pcg_rel_tol=1e-12)
+        try:
+            o.set_graph(g); r = o.optimize(n)
+        finally:
+            o.close()
+        assert ref["stop"] == want
+        assert (r["stop"], r["iters"]) == (ref["stop"], ref["iters"]), (want, r["stop"], r["iters"], ref["iters"])
+
+
 def test_gauge_free_graph_on_the_device():
     """No fixed vertex (singular H): same chi^2 trajectory as the reference's rank-revealing QR; every multigrid solve
     breaks down on the singular coarsest matrix and is repeated with block-Jacobi (counted in pcg_fallbacks)."""

@@ -75,6 +75,17 @@ def no_fixed_vertex():
     return g
 
 
+def non_rigid_odom_measurements():
+    """The wire carries an ODOM measurement as ANY 3x3 (DeserializeGraph.h:99-111) and EdgeSe2.h:32 inverts it as
+    such: a few measurements with shear / scale in the upper-left block and a last row that is not (0, 0, 1)."""
+    g = base()
+    od = np.where(g.e_type == 0)[0]
+    m = g.e_meas.copy()
+    m[od[1]] = m[od[1]] * np.array([1.03, 1.0, 1.0, 1.0, 0.98, 1.0, 1.0, 1.0, 1.0]) + np.array([0, 0.02, 0, -0.01, 0, 0, 0, 0, 0])
+    m[od[4]] = m[od[4]] + np.array([0, 0, 0, 0, 0, 0, 0.002, -0.001, 0.01])
+    return GraphArrays(g.v_id, g.v_type, g.v_pos, g.e_type, g.e_ids, m, g.e_inf, g.fixed)
+
+
 def near_optimum(rounds=6):
     """tiny_a re-started from its own optimised vertices until the first step is shorter than 1e-3: the run then stops
     on the reference's third rule ("CONVERGED", OptimizerCpu.h:173-177) after one iteration."""
@@ -94,5 +105,6 @@ CASES = {
     "sparse_large_ids": sparse_large_ids,
     "landmark_edges_only": landmark_edges_only,
     "pose_graph_without_landmarks": pose_graph_without_landmarks,
+    "non_rigid_odom_measurements": non_rigid_odom_measurements,
     "self_loop_dup_edges": self_loop_and_duplicate_edges,
 }

@@ -180,6 +180,7 @@ template <typename T> struct Engine : IEngine {
         allocs.clear();
         if (h_state) { (void)hipHostFree(h_state); h_state = nullptr; }
         if (h_scratch) { (void)hipHostFree(h_scratch); h_scratch = nullptr; }
+        if (h_rho) { (void)hipHostFree(h_rho); h_rho = nullptr; }
         have_graph_data = false;
     }
 

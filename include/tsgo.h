@@ -72,7 +72,7 @@ enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_
 typedef struct tsgo_stats {
     int32_t iterations_run;              /* Gauss-Newton linearisations performed */
     int32_t stop_reason;                 /* TSGO_STOP_*; rules of OptimizerCpu.h:140-153,167-177 */
-    double chi2[TSGO_MAX_TRACE];         /* robustified chi^2 at each linearisation (`err`, :117) */
+    double chi2[TSGO_MAX_TRACE];         /* robustified chi^2 at each linearisation (`err`, :117); the first TSGO_MAX_TRACE of them */
     int32_t pcg_iters[TSGO_MAX_TRACE];   /* PCG iterations of each solve */
     double last_delta_norm;              /* ||delta||_2 of the last solve (unscaled, :173) */
     double ms_total, ms_linearize, ms_solve, ms_update;   /* device time, hipEvent */
@@ -80,7 +80,9 @@ typedef struct tsgo_stats {
     int64_t n_pose, n_lm, n_odom_edges, n_lm_edges;
     int64_t pcg_iters_total;
     int32_t pcg_fallbacks;               /* solves repeated with block-Jacobi after a multigrid breakdown */
-    int32_t reserved;
+    int32_t trace_len;                   /* entries of chi2[] / pcg_iters[] that are valid: min(iterations_run, TSGO_MAX_TRACE) */
+    double chi2_last;                    /* chi^2 of the LAST linearisation (`Summary() error`, OptimizerCpu.h:182), also when the
+                                            run is longer than the trace */
 } tsgo_stats;
 
 /* Fills cfg with defaults. */

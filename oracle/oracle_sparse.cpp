@@ -74,8 +74,9 @@ struct Twin {
         return std::string();
     }
 
-    std::string enable_amg() {
-        std::string e = tsgo::build_amg(pr, amg);
+    // world > 1: replicated hierarchy, level-0 blocks summed from per-shard partials (host/amg.h: build_amg_sharded)
+    std::string enable_amg(const tsgo_graph& g) {
+        std::string e = pr.world > 1 ? tsgo::build_amg_sharded(g, pr, amg) : tsgo::build_amg(pr, amg);
         if (!e.empty()) return e;
         hier.alloc(amg);
         res0.assign((size_t)P * 3, 0); s0.assign((size_t)P * 3, 0);
@@ -96,6 +97,7 @@ struct Twin {
                 const int k = L.A.col[b];
                 double* o = &A[(size_t)b * 9];
                 if (k == i) {
+                    if (pr.rank != 0) { for (int m = 0; m < 9; ++m) o[m] = 0; continue; }     // the all-reduced diagonal: one rank contributes it
                     const double* o18 = &part[(size_t)i * 18];
                     const double m[6] = {o18[0] - o18[9], o18[1] - o18[10], o18[2] - o18[11], o18[3] - o18[12], o18[4] - o18[13], o18[5] - o18[14]};
                     o[0] = m[0]; o[1] = m[1]; o[2] = m[2]; o[3] = m[1]; o[4] = m[3]; o[5] = m[4]; o[6] = m[2]; o[7] = m[4]; o[8] = m[5];
@@ -129,6 +131,7 @@ struct Twin {
                 }
             }
         }
+        allreduce(A.data(), (int64_t)((size_t)L.A.nnz() * 9));     // tsgo_hip.hip: launch_amg_setup
     }
 
     // z = M^-1 r by one V(1,1) cycle (level 0 uses the implicit Schur product)
@@ -139,12 +142,12 @@ struct Twin {
             if (!amg.levels.empty()) for (int k = 0; k < 3; ++k) z[3 * (size_t)i + k] *= w0;
         }
         if (amg.levels.empty()) return;
-        schur_lm(z); schur_pose(z, s0);
+        schur_lm(z); schur_pose(z, s0); allreduce(s0.data(), (int64_t)s0.size());
         for (size_t k = 0; k < s0.size(); ++k) res0[k] = r[k] - s0[k];
         hier.restrict_to(0, res0, hier.r[1]);
         hier.cycle(1);
         hier.prolong_add(0, hier.z[1], z);
-        schur_lm(z); schur_pose(z, s0);
+        schur_lm(z); schur_pose(z, s0); allreduce(s0.data(), (int64_t)s0.size());
         for (int i = 0; i < P; ++i) {
             double d0, d1, d2;
             tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i] - s0[3 * (size_t)i], r[3 * (size_t)i + 1] - s0[3 * (size_t)i + 1], r[3 * (size_t)i + 2] - s0[3 * (size_t)i + 2], d0, d1, d2);
@@ -491,7 +494,7 @@ int oracle_sparse_step(GRAPH_ARGS, double pcg_tol, int max_cg, int precond, int 
     Twin tw; tw.hook = hook; tw.hook_ctx = ctx;
     const tsgo_graph g = make_view(GRAPH_PASS);
     if (!tw.init(g, rank, world).empty()) return -2;
-    if (precond == 1 && !tw.enable_amg().empty()) return -5;
+    if (precond == 1 && !tw.enable_amg(g).empty()) return -5;
     const double gamma0 = tw.linearize();
     bool ok; *cg_iters = tw.solve_with_fallback(gamma0, pcg_tol, max_cg, &ok);
     std::vector<double> dl; tw.backsub(dl);
@@ -509,7 +512,7 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
     Twin tw; tw.hook = hook; tw.hook_ctx = ctx;
     const tsgo_graph g = make_view(GRAPH_PASS);
     if (!tw.init(g, rank, world).empty()) return -2;
-    if (precond == 1 && !tw.enable_amg().empty()) return -5;
+    if (precond == 1 && !tw.enable_amg(g).empty()) return -5;
     std::memcpy(v_pos_out, v_pos, sizeof(double) * 3 * (size_t)nV);
     double prevErr = -1; int penalty = 0;
     std::vector<double> xprev;

@@ -1,0 +1,89 @@
+"""A checker for the BIG configurations that shares no code with the product.
+
+The CPU twin (oracle/oracle_sparse.cpp) reuses the product's slot-table builder and per-edge arithmetic, so agreement
+with it above the sizes the dense restatement reaches cannot expose a mistake the two have in common.  This module
+uses ONLY oracle/oracle_dense.cpp's own per-edge functions (lm_edge / odom_edge, exported as oracle_edge_eval_f64 —
+the restatement of remote/graph/edge/EdgeSe2Point2d.h:27-70 and EdgeSe2.h:23-38, O(E)) and numpy:
+
+  chi2, gradient b, diagonal blocks of H      as OptimizerCpu.h:88-119,132-138 accumulates them
+  H @ delta, matrix-free                      J^T (Omega_w (J delta)) + gauge, edge by edge
+
+so that a device linearisation and a device solve can be checked at 100k and 1M poses:  ||H delta - b|| / ||b||.
+"""
+import numpy as np
+
+from oracle import oracle
+
+HUBER_DELTA = 1.5          # remote/optimizer/OptimizerCpu.h:92
+GAUGE = 1e6                # :136
+
+
+class Linearisation:
+    """Per-edge Jacobians and Huber-scaled weights of one graph at its current vertex positions."""
+
+    def __init__(self, g):
+        o = oracle.Graph(g.v_id, g.v_type, g.v_pos, g.e_type, g.e_ids, g.e_meas, g.e_inf, g.fixed)
+        e, A, B = oracle.edge_eval(o)
+        E, V = len(g.e_type), len(g.v_id)
+        lm = g.e_type == 1
+        # uniform 3x3 blocks: an LM edge's 2x3 / 2x2 Jacobians sit in the top rows (third residual row = 0)
+        A3 = A.reshape(E, 3, 3).copy(); B3 = B.reshape(E, 3, 3).copy()
+        A3[lm] = 0; B3[lm] = 0
+        A3[lm, :2, :] = A[lm, :6].reshape(-1, 2, 3)
+        B3[lm, :2, :2] = B[lm, :4].reshape(-1, 2, 2)
+        w = g.e_inf.copy(); w[lm, 2] = 0
+        e = e.copy(); e[lm, 2] = 0
+        chi = (w * e * e).sum(axis=1)                                   # e^T Omega e  (:91)
+        tail = chi > HUBER_DELTA ** 2                                   # robustify (:36-46)
+        sq = np.sqrt(np.where(tail, chi, 1.0))
+        rho = np.where(tail, 2 * sq * HUBER_DELTA - HUBER_DELTA ** 2, chi)
+        scale = np.where(tail, HUBER_DELTA / sq, 1.0)
+        self.n_tail = int(tail.sum())
+        self.chi2 = float(rho.sum())                                    # err += rho (:117)
+        self.w = w * scale[:, None]                                     # Omega_w (:93)
+        self.A, self.B, self.e = A3, B3, e
+        order = np.argsort(g.v_id, kind="stable"); ids = g.v_id[order]
+        self.i1 = order[np.searchsorted(ids, g.e_ids[:, 0])]
+        self.i2 = order[np.searchsorted(ids, g.e_ids[:, 1])]
+        self.V = V
+        self.gauge = np.zeros(V)
+        for f in g.fixed:                                               # once per occurrence (:132-138)
+            self.gauge[order[np.searchsorted(ids, f)]] += GAUGE
+        self.dims = np.where(g.v_type == 0, 3, 2)
+
+    def _scatter(self, idx, vals):
+        out = np.zeros((self.V,) + vals.shape[1:])
+        flat = out.reshape(self.V, -1); v = vals.reshape(len(idx), -1)
+        for k in range(v.shape[1]):
+            flat[:, k] = np.bincount(idx, weights=v[:, k], minlength=self.V)
+        return out
+
+    def gradient(self):
+        """b = -sum J^T Omega_w e per vertex, (V, 3) (AddSegment subtracts: MatrixEigen.h:93-96)."""
+        we = self.w * self.e
+        return -(self._scatter(self.i1, np.einsum("eki,ek->ei", self.A, we)) +
+                 self._scatter(self.i2, np.einsum("eki,ek->ei", self.B, we)))
+
+    def diag_blocks(self):
+        """Diagonal 3x3 blocks of H incl. the gauge term, (V, 9) row-major; landmarks use the leading 2x2."""
+        d = (self._scatter(self.i1, np.einsum("eki,ek,ekj->eij", self.A, self.w, self.A)) +
+             self._scatter(self.i2, np.einsum("eki,ek,ekj->eij", self.B, self.w, self.B)))
+        for k in range(3):
+            d[:, k, k] += np.where(k < self.dims, self.gauge, 0.0)
+        return d.reshape(self.V, 9)
+
+    def apply_H(self, delta):
+        """H @ delta for a per-vertex (V, 3) delta (third component of a landmark ignored)."""
+        d = np.where(np.arange(3)[None, :] < self.dims[:, None], delta, 0.0)
+        jd = np.einsum("eki,ei->ek", self.A, d[self.i1]) + np.einsum("eki,ei->ek", self.B, d[self.i2])
+        wjd = self.w * jd
+        out = (self._scatter(self.i1, np.einsum("eki,ek->ei", self.A, wjd)) +
+               self._scatter(self.i2, np.einsum("eki,ek->ei", self.B, wjd)))
+        return out + self.gauge[:, None] * d
+
+    def residual_of(self, delta):
+        """||H delta - b|| / ||b||."""
+        b = self.gradient()
+        r = self.apply_H(delta) - b
+        mask = np.arange(3)[None, :] < self.dims[:, None]
+        return float(np.linalg.norm(r[mask]) / np.linalg.norm(b[mask]))

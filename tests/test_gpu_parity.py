@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(scope="module", params=["amg", "jacobi"])
 def opt(request):
     """Both preconditioners go through every parity check: the multigrid V-cycle (default) and the
-    block-Jacobi fallback (the one edge-sharded runs use)."""
+    block-Jacobi fallback."""
     o = HipOptimizer(pcg_rel_tol=1e-12, preconditioner=request.param)
     yield o
     o.close()
@@ -148,14 +148,15 @@ def test_warm_start_and_lagged_hierarchy_change_the_work_not_the_answer(monkeypa
     assert ra["cg_iters"][1:].sum() < rb["cg_iters"][1:].sum() + 3 * 9   # lag costs a few iterations, warm start saves more or about as many
 
 
-def test_collective_path_over_rccl_with_a_single_rank_communicator():
-    """The edge-sharded path (eager launches, block-Jacobi PCG, ncclAllReduce of the pose partials per GN iteration
-    and of the Schur product per PCG iteration) on the one GPU this box has: a world-size-1 RCCL communicator makes
-    the engine take it.  Same answer as the dense reference path; the 2-shard arithmetic is covered on CPU by
-    tests/test_sharded_gloo.py."""
+@pytest.mark.parametrize("precond", ["amg", "jacobi"])
+def test_collective_path_over_rccl_with_a_single_rank_communicator(precond):
+    """The edge-sharded path (eager launches, ncclAllReduce of the pose partials per GN iteration, of every Schur product —
+    three per multigrid-preconditioned PCG iteration, one with block-Jacobi — and of the level-0 blocks per hierarchy
+    build) on the one GPU this box has: a world-size-1 RCCL communicator makes the engine take it.  Same answer as the
+    dense reference path; the multi-shard arithmetic is covered on CPU by tests/test_sharded_gloo.py."""
     g = util.c1_arrays()
     ref = oracle.optimize(util.to_oracle(g), 6, mode="cpp", solver="chol")
-    o = HipOptimizer(pcg_rel_tol=1e-12, rank=0, world=1)
+    o = HipOptimizer(pcg_rel_tol=1e-12, rank=0, world=1, preconditioner=precond)
     try:
         o.comm_init(o.comm_unique_id())
         o.set_graph(g); r = o.optimize(6); v = o.vertices()
@@ -163,7 +164,34 @@ def test_collective_path_over_rccl_with_a_single_rank_communicator():
         o.close()
     np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-10)
     assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-9
-    assert r["cg_iters"].min() > 30        # block-Jacobi counts: the collective path, not the multigrid one
+    assert abs(r["delta_norm"] - ref["delta_norm"]) < 1e-8
+    if precond == "jacobi":
+        assert r["cg_iters"].min() > 30        # block-Jacobi counts
+    else:
+        assert r["cg_iters"].max() < 30 and r["fallbacks"] == 0, r["cg_iters"]      # the multigrid cycle ran through the collectives
+
+
+def test_collective_path_at_config_2_size_keeps_multigrid_iteration_counts():
+    """BASELINE config 2 (10k poses) through the collective path with a one-rank communicator: the same chi^2 trajectory
+    and vertices as the hipGraph single-GPU path, multigrid iteration counts (block-Jacobi needs ~2 800 here)."""
+    g = synth.make_config("c2_10k")
+    runs = {}
+    for name in ("graph", "collective"):
+        o = HipOptimizer(pcg_rel_tol=1e-12, rank=0, world=1)
+        try:
+            if name == "collective":
+                o.comm_init(o.comm_unique_id())
+            o.set_graph(g); r = o.optimize(6); runs[name] = (r, o.vertices())
+        finally:
+            o.close()
+    (ra, va), (rb, vb) = runs["graph"], runs["collective"]
+    np.testing.assert_array_equal(ra["chi2"], rb["chi2"])              # same kernels, same order: same bits
+    np.testing.assert_array_equal(ra["cg_iters"], rb["cg_iters"])
+    np.testing.assert_array_equal(va, vb)
+    assert rb["cg_iters"].max() < 60 and rb["fallbacks"] == 0, rb["cg_iters"]
+    ref = oracle.sparse_optimize(util.to_oracle(g), 6, pcg_tol=1e-12, precond="jacobi")
+    np.testing.assert_allclose(rb["chi2"], ref["chi2"], rtol=1e-9)
+    assert util.max_vertex_diff(vb, ref["v_pos"], g.v_type) < 1e-7
 
 
 def test_bench_tolerance_meets_the_north_star_bar():

@@ -1,6 +1,8 @@
-"""The edge-sharded algorithm across TWO CPU processes (gloo): product shard planner + the CPU twin with
-an all-reduce hook in exactly the places where the HIP path calls RCCL (tsgo_hip.hip: after lin_pose,
-after schur_pose, after the landmark update).  Compared with the unsharded run."""
+"""The edge-sharded algorithm across CPU processes (gloo): product shard planner (+ the product's sharded multigrid
+pattern builder, host/amg.cpp: build_amg_sharded) + the CPU twin with an all-reduce hook in exactly the places where
+the HIP path calls RCCL (tsgo_hip.hip: after lin_pose, after every schur_pose — three per multigrid-preconditioned
+PCG iteration —, after the level-0 blocks of a hierarchy build, after the landmark update).  Compared with the
+unsharded run, with both preconditioners."""
 import os
 import socket
 import sys
@@ -19,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, n_poses):
+def _worker(rank, world, port, out_dir, n_poses, precond):
     sys.path.insert(0, ROOT)
     torch.set_num_threads(2)      # also sizes the twin's OpenMP loops (same libgomp)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -34,7 +36,7 @@ def _worker(rank, world, port, out_dir, n_poses):
         calls[0] += 1
         dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM)
 
-    r = oracle.sparse_optimize(util.to_oracle(g), 3, pcg_tol=1e-12, rank=rank, world=world, allreduce=allreduce)
+    r = oracle.sparse_optimize(util.to_oracle(g), 3, pcg_tol=1e-12, rank=rank, world=world, allreduce=allreduce, precond=precond)
     # landmarks are shard-local: owned ones moved, the others still hold their input value
     moved = np.any(r["v_pos"] != g.v_pos, axis=1) & (g.v_type == 1)
     lm = np.where(moved[:, None], r["v_pos"], 0.0)
@@ -47,19 +49,23 @@ def _worker(rank, world, port, out_dir, n_poses):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2])
-def test_two_process_sharded_run_matches_single_process(tmp_path, world):
-    n_poses = 300
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_poses), nprocs=world, join=True)
+@pytest.mark.parametrize("world,precond,n_poses", [(2, "jacobi", 300), (2, "amg", 1500), (3, "amg", 700)])
+def test_sharded_run_across_processes_matches_single_process(tmp_path, world, precond, n_poses):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_poses, precond), nprocs=world, join=True)
     from oracle import oracle
     from tests import util
     from toyslam_amd import synth
     g = synth.make(n_poses, 10, loop_closures=30, seed=11)
-    ref = oracle.sparse_optimize(util.to_oracle(g), 3, pcg_tol=1e-12)
+    ref = oracle.sparse_optimize(util.to_oracle(g), 3, pcg_tol=1e-12, precond=precond)
     outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for o in outs:
         np.testing.assert_allclose(o["chi2"], ref["chi2"], rtol=1e-11)
         assert util.max_vertex_diff(o["v"], ref["v_pos"], g.v_type) < 1e-9
         assert o["calls"] > 10                       # the hook really carried the reduction
         assert np.all(o["owners"][g.v_type == 1] <= 1)   # no landmark is owned twice
-    np.testing.assert_array_equal(outs[0]["chi2"], outs[1]["chi2"])      # ranks agree bit for bit
+        if precond == "amg":                         # multigrid iteration counts, not block-Jacobi ones, and the same
+            assert o["cg"].max() < 60, o["cg"]       # work as the unsharded multigrid run (+-2: the level-0 sums differ in order)
+            assert np.all(np.abs(o["cg"] - ref["cg_iters"]) <= 2), (o["cg"], ref["cg_iters"])
+    for o in outs[1:]:
+        np.testing.assert_array_equal(outs[0]["chi2"], o["chi2"])      # ranks agree bit for bit
+        np.testing.assert_array_equal(outs[0]["cg"], o["cg"])          # ... and take the same decisions (or RCCL would hang)

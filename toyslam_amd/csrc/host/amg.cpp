@@ -527,4 +527,44 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
     return std::string();
 }
 
+std::string build_amg_sharded(const tsgo_graph& g, const Problem& local, AmgSym& out) {
+    Problem full;
+    BuildOptions bo; bo.lanes_per_pose = local.by_pose.G; bo.lanes_per_lm = local.by_lm.G;
+    std::string err = build_problem(g, bo, full);
+    if (!err.empty()) return err;
+    if (full.P != local.P || full.pose_vertex != local.pose_vertex) return "shard and whole-graph pose numbering differ";
+    AmgSym S;
+    err = build_amg(full, S);
+    if (!err.empty()) return err;
+    // edge -> slot of the LOCAL tables (LM edges: by_pose slot; ODOM edges: one slot per owned endpoint)
+    const size_t nE = (size_t)std::max(0, g.n_edges);
+    std::vector<uint32_t> lm_slot(nE, kNoEdge), od_slot(2 * nE, kNoEdge);
+    for (size_t s = 0; s < local.by_pose.edge.size(); ++s) if (local.by_pose.edge[s] != kNoEdge) lm_slot[local.by_pose.edge[s]] = (uint32_t)s;
+    for (size_t s = 0; s < local.odom.edge.size(); ++s)
+        if (local.odom.edge[s] != kNoEdge) od_slot[2 * (size_t)local.odom.edge[s] + ((local.odom.idx[s] & kDirBit) ? 1 : 0)] = (uint32_t)s;
+    SchurLists mine;
+    const size_t nb = S.schur.ptr.size() - 1;
+    mine.ptr.assign(1, 0); mine.od_ptr.assign(1, 0);
+    mine.ptr.reserve(nb + 1); mine.od_ptr.reserve(nb + 1);
+    for (size_t b = 0; b < nb; ++b) {
+        for (int q = S.schur.ptr[b]; q < S.schur.ptr[b + 1]; ++q) {
+            const uint32_t ei = full.by_pose.edge[S.schur.slot_i[q]], ek = full.by_pose.edge[S.schur.slot_k[q]];
+            const uint32_t si = lm_slot[ei], sk = lm_slot[ek];
+            if (si == kNoEdge) continue;                       // the shared landmark belongs to another shard
+            if (sk == kNoEdge) return "a landmark's edges are split across shards";
+            mine.slot_i.push_back(si); mine.slot_k.push_back(sk);
+        }
+        mine.ptr.push_back((int)mine.slot_i.size());
+        for (int q = S.schur.od_ptr[b]; q < S.schur.od_ptr[b + 1]; ++q) {
+            const size_t fs = S.schur.od_slot[q];
+            const uint32_t s = od_slot[2 * (size_t)full.odom.edge[fs] + ((full.odom.idx[fs] & kDirBit) ? 1 : 0)];
+            if (s != kNoEdge) mine.od_slot.push_back(s);       // the row pose is owned by this shard
+        }
+        mine.od_ptr.push_back((int)mine.od_slot.size());
+    }
+    S.schur = std::move(mine);
+    out = std::move(S);
+    return std::string();
+}
+
 }  // namespace tsgo

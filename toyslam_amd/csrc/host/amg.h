@@ -83,4 +83,11 @@ struct AmgSym {
 // Builds the hierarchy for a single-shard problem.  Returns "" or an error text.
 std::string build_amg(const Problem& pr, AmgSym& out);
 
+// Edge-sharded runs (Problem::world > 1): the hierarchy is REPLICATED — every rank builds the same patterns from the
+// whole graph — but the level-0 matrix is summed from per-rank partial blocks: `out.schur` lists, for every S block,
+// only the landmark pairs / odometry rows THIS shard owns, as slots of `local`'s own tables; the ranks' partial
+// blocks are then all-reduced (tsgo_hip.hip: launch_amg_setup).  The diagonal blocks come from the all-reduced
+// linearisation partials and are contributed by rank 0 alone.
+std::string build_amg_sharded(const tsgo_graph& g, const Problem& local, AmgSym& out);
+
 }  // namespace tsgo

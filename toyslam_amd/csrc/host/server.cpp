@@ -78,6 +78,15 @@ struct Server {
     std::mutex pool_mutex;
     std::condition_variable pool_cv;
     int iterations = 10;
+    // connection threads are bounded: past kMaxConnections the acceptor stops accepting (the kernel's listen backlog
+    // holds the rest) until one ends.  The reference serves every connection from ONE thread (main.cpp:36-42).
+    static constexpr int kMaxConnections = 64;
+    int live_connections = 0;
+    std::mutex conn_mutex;
+    std::condition_variable conn_cv;
+    void connection_begin() { std::unique_lock<std::mutex> lock(conn_mutex); conn_cv.wait(lock, [this] { return live_connections < kMaxConnections; }); ++live_connections; }
+    void connection_end() { { std::lock_guard<std::mutex> lock(conn_mutex); --live_connections; } conn_cv.notify_all(); }
+    void drain() { std::unique_lock<std::mutex> lock(conn_mutex); conn_cv.wait(lock, [this] { return live_connections == 0; }); }
 
     // an engine handle for one request: an idle one, a new one while fewer than max_engines exist, else wait
     tsgo_optimizer* acquire() {
@@ -122,8 +131,7 @@ struct Server {
                 if (st.stop_reason == TSGO_STOP_WORSE) std::cout << "Error is getting worse\n";       // OptimizerCpu.h:146
                 if (st.stop_reason == TSGO_STOP_PLATEAU) std::cout << "Plateau: NO MORE OPT\n";       // :169
                 if (st.stop_reason == TSGO_STOP_CONVERGED) std::cout << "CONVERGED\n";                // :175
-                const int last = st.iterations_run > 0 ? std::min(st.iterations_run, TSGO_MAX_TRACE) - 1 : 0;
-                std::cout << "Summary() error = " << st.chi2[last] << std::endl;                       // :182
+                std::cout << "Summary() error = " << st.chi2_last << std::endl;                        // :182
                 std::cout << " [hip] iterations=" << st.iterations_run << " pcg_iters=" << st.pcg_iters_total
                           << " setup=" << st.ms_setup << "ms linearize=" << st.ms_linearize << "ms solve=" << st.ms_solve
                           << "ms update=" << st.ms_update << "ms" << std::endl;
@@ -208,10 +216,16 @@ int main(int argc, char* argv[]) {
         freeaddrinfo(res);
         std::cout << "listening" << std::endl;
         for (;;) {                                                               // ConnectionManagerServer.h:46-61
+            srv.connection_begin();                                              // waits while kMaxConnections are being served
             const int fd = ::accept(lfd, nullptr, nullptr);
-            if (fd < 0) { if (errno == EINTR) continue; std::cerr << "accept: " << std::strerror(errno) << std::endl; break; }
-            std::thread([&srv, fd] { srv.connection(fd); }).detach();
+            if (fd < 0) {
+                srv.connection_end();
+                if (errno == EINTR) continue;
+                std::cerr << "accept: " << std::strerror(errno) << std::endl; break;
+            }
+            std::thread([&srv, fd] { srv.connection(fd); srv.connection_end(); }).detach();
         }
+        srv.drain();                                                             // the acceptor failed: let the requests in flight finish
         for (tsgo_optimizer* o : srv.idle) tsgo_destroy(o);
     } catch (std::exception& e) {
         std::cerr << "ConnectionManager error: " << e.what() << std::endl;       // main.cpp:44-47

@@ -56,12 +56,17 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
                                                          const uint32_t* __restrict__ slot_k, const int* __restrict__ optr,
                                                          const uint32_t* __restrict__ oslot, Table<T> tb, const T* __restrict__ od_dyn,
                                                          size_t od_slots, const T* __restrict__ lmrec, const T* __restrict__ ps,
-                                                         const T* __restrict__ part, HT<T>* __restrict__ A) {
+                                                         const T* __restrict__ part, HT<T>* __restrict__ A, int diag_on) {
     const int b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= nnz) return;
     const int i = blk_row[b], k = blk_col[b];
     HT<T>* o = A + (size_t)b * 9;
     if (i == k) {
+        if (!diag_on) {       // edge-sharded: the (already all-reduced) diagonal is contributed by one rank only
+#pragma unroll
+            for (int m = 0; m < 9; ++m) o[m] = 0;
+            return;
+        }
         const T* p = part + (size_t)i * 18;
         const T m0 = p[0] - p[9], m1 = p[1] - p[10], m2 = p[2] - p[11], m3 = p[3] - p[12], m4 = p[4] - p[13], m5 = p[5] - p[14];
         o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m1; o[4] = m3; o[5] = m4; o[6] = m2; o[7] = m4; o[8] = m5;

@@ -243,10 +243,10 @@ template <typename T> struct Engine : IEngine {
     // The hierarchy's patterns are built by a host thread (host/amg.cpp) while this thread uploads state and slot tables.
     std::thread amg_builder;
     std::string amg_builder_error;
-    void start_amg_builder() {
-        amg_builder = std::thread([this] {
+    void start_amg_builder(const tsgo_graph& g) {
+        amg_builder = std::thread([this, &g] {      // g is borrowed for the whole tsgo_set_graph call, which joins this thread
             const auto t0 = std::chrono::steady_clock::now();
-            amg_builder_error = build_amg(pr, amg);
+            amg_builder_error = pr.world > 1 ? build_amg_sharded(g, pr, amg) : build_amg(pr, amg);
             ms_amg_symbolic = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         });
     }
@@ -348,8 +348,8 @@ template <typename T> struct Engine : IEngine {
         lap("layout (build_problem)");
         const int P = pr.P, L = pr.L;
         if (P == 0) return set_error(-2, "tsgo_set_graph: the graph has no Se2 vertex");
-        amg_on = cfg.preconditioner == 1 && !collective() && pr.P > kCoarsestMax;
-        if (amg_on) start_amg_builder();
+        amg_on = cfg.preconditioner == 1 && pr.P > kCoarsestMax;
+        if (amg_on) start_amg_builder(g);
         struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{amg_builder};   // on every error path too
         // state
         std::vector<double> ps_h((size_t)P * 4), th_h(P);
@@ -424,24 +424,32 @@ template <typename T> struct Engine : IEngine {
     }
     // S * (vector in zc) -> sbuf, dot partials behind it.  low: read the f32 copy of the slot planes (the two
     // products inside the multigrid cycle; never the product PCG itself takes).
-    void launch_matvec(int slot, bool with_rz = false, bool low = false) {
+    // Edge-sharded runs: every rank's passes cover its own landmarks (and the ODOM rows / diagonal blocks of its own
+    // poses), so what lands in sbuf is a PARTIAL product and partial dots: one all-reduce of [3P | nbP] makes both whole
+    // on every rank.  (r, z) partials are computed redundantly from replicated vectors and need no reduction.
+    int launch_matvec(int slot, bool with_rz = false, bool low = false) {
         if (low) {
             if (tl.n_slices > 0) LAUNCH_GML(pr.by_lm.G, k_schur_lm, 0, 1, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
             LAUNCH_GML1(pr.by_pose.G, k_schur_pose, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
                         (const T*)nullptr, rzpart);
-            return;
+        } else {
+            if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
+            LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
+                     (const T*)(with_rz ? r : nullptr), rzpart);
         }
-        if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
-        LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
-                 (const T*)(with_rz ? r : nullptr), rzpart);
+        return allreduce(sbuf, (size_t)pr.P * 3 + nbP);
     }
     static int grid_for(int n, int per_thread_lanes = 1) { return std::max(1, (int)(((size_t)n * per_thread_lanes + kBlock - 1) / kBlock)); }
 
     // numeric multigrid setup for the current linearisation (after lin + finalize)
-    void launch_amg_setup() {
+    int launch_amg_setup() {
         DevLevel<T>& L0 = lv[0];
+        // sharded: off-diagonal blocks are partial sums over this rank's landmarks and ODOM rows; the diagonal (from the
+        // all-reduced linearisation partials, identical everywhere) is contributed by rank 0 alone; one all-reduce
+        // makes level 0 whole and identical on every rank, everything below it is then computed redundantly
         hipLaunchKernelGGL((k_schur_blocks<T>), dim3(grid_for(L0.nnzA)), dim3(kBlock), 0, stream, L0.nnzA, L0.A_row, L0.A_col, sc_ptr, sc_si, sc_sk,
-                           sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A);
+                           sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A, pr.rank == 0 ? 1 : 0);
+        if (int rc = allreduce_h(L0.A, (size_t)L0.nnzA * 9)) return rc;
         for (size_t l = 0; l < lv.size(); ++l) {
             DevLevel<T>& L = lv[l];
             H* Anext = l + 1 < lv.size() ? lv[l + 1].A : A_last;
@@ -459,6 +467,7 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL((k_mirror_blocks<T>), dim3(grid_for(L.nnzNext, 9)), dim3(kBlock), 0, stream, L.nnzNext, (const int*)L.as_mirror, Anext);
         }
         hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kDenseThreads), 0, stream, nb_last, last_ptr, last_col, (const H*)A_last, inv_last);
+        return 0;
     }
 
     static int lanes_for(double avg_row) { return avg_row <= 4 ? 4 : (avg_row <= 12 ? 8 : (avg_row <= 40 ? 32 : 64)); }
@@ -521,10 +530,10 @@ template <typename T> struct Engine : IEngine {
     // zc[.][0..2] = V(1,1)-cycle(r).  On entry zc already holds the level-0 pre-smoothing Minv r
     // (written by pose_finalize / k_cg_step).  Level l >= 1 keeps r, z (pre-smoothed by the restriction
     // above it), res and the post-smoothed result z2.
-    void launch_vcycle(int slot) {
+    int launch_vcycle(int slot) {
         const CgState<T>* s = st[slot];
         const size_t nl = lv.size();              // explicit levels 0 .. nl-1, dense level below
-        launch_matvec(slot, false, low_cycle);
+        if (int rc = launch_matvec(slot, false, low_cycle)) return rc;
         {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
@@ -573,8 +582,9 @@ template <typename T> struct Engine : IEngine {
             // nu post-sweeps after nu-1 pre-swaps: the result sits in L.z2 for every nu (odd+odd / even+even swaps)
         }
         launch_prolong(lv[0], nl > 1 ? (const T*)lv[1].z2 : (const T*)z_last, zc, kPoseRec, s);
-        launch_matvec(slot, false, low_cycle);
+        if (int rc = launch_matvec(slot, false, low_cycle)) return rc;
         hipLaunchKernelGGL((k_smooth0<T, 1>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, (const T*)omega_dev, s);
+        return 0;
     }
     void launch_cg_step(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
@@ -582,9 +592,16 @@ template <typename T> struct Engine : IEngine {
                            (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, (const T*)omega_dev, tol2, std::min(cfg.pcg_max_iters, kAmgIterCap), (const T*)gscale_dev);
     }
     // one PCG iteration reading state slot `slot`, writing slot^1
-    void launch_iteration(int slot) {
-        if (amg_on) { launch_vcycle(slot); launch_matvec(slot, true); launch_cg_step(slot); }
-        else { launch_matvec(slot); launch_cg_update(slot); }
+    int launch_iteration(int slot) {
+        if (amg_on) {
+            if (int rc = launch_vcycle(slot)) return rc;
+            if (int rc = launch_matvec(slot, true)) return rc;
+            launch_cg_step(slot);
+        } else {
+            if (int rc = launch_matvec(slot)) return rc;
+            launch_cg_update(slot);
+        }
+        return 0;
     }
     int chunk() const { return amg_on ? kChunkAmg : kChunk; }
     void launch_cg_update(int slot) {
@@ -602,10 +619,16 @@ template <typename T> struct Engine : IEngine {
         NCCL_OK(ncclAllReduce(buf, buf, n, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream));
         return 0;
     }
+    int allreduce_h(H* buf, size_t n) {       // hierarchy storage type (f32 unless TSGO_HIER_F64)
+        if (!collective()) return 0;
+        if (!comm) return set_error(-12, "world > 1 but tsgo_comm_init was not called");
+        NCCL_OK(ncclAllReduce(buf, buf, n, sizeof(H) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream));
+        return 0;
+    }
     int capture_cg_graph() {
         hipGraph_t graph = nullptr;
         HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
-        for (int j = 0; j < chunk(); ++j) launch_iteration(j & 1);
+        for (int j = 0; j < chunk(); ++j) if (int rc = launch_iteration(j & 1)) return rc;     // never collective: no RCCL call is captured
         HIP_OK(hipStreamEndCapture(stream, &graph));
         HIP_OK(hipGraphInstantiate(&cg_graph, graph, nullptr, nullptr, 0));
         HIP_OK(hipGraphDestroy(graph));
@@ -623,7 +646,7 @@ template <typename T> struct Engine : IEngine {
             // have served hier_max_age solves or the last solve took kHierSlack iterations more than the first one did.
             const bool refresh = hier_age < 0 || hier_age >= hier_max_age || iters_last > iters_fresh + hier_slack;
             if (refresh) {
-                launch_amg_setup();
+                if (int rc = launch_amg_setup()) return rc;
                 hier_age = 0;
                 if (lin_count++ % kRhoEvery == 0) {
                     if (int rc = estimate_damping()) return rc;
@@ -647,8 +670,7 @@ template <typename T> struct Engine : IEngine {
     // rule keeps measuring against the right-hand side: gamma0 is scaled by (b^T D^-1 b) / (r0^T D^-1 r0).
     int launch_warm() {
         hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, (T)(1.0 - kStepScale));
-        launch_matvec(0);
-        if (int rc = allreduce(sbuf, (size_t)pr.P * 3 + nbP)) return rc;
+        if (int rc = launch_matvec(0)) return rc;
         hipLaunchKernelGGL((k_warm_residual<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)minv, r, zc, (const T*)(amg_on ? omega_dev : one_dev), npart);
         hipLaunchKernelGGL((k_warm_scale<T>), dim3(1), dim3(kBlock), 0, stream, nbC, (const T*)gpart[0], (const T*)npart, amg_on ? (T*)nullptr : gpart[0], gscale_dev);
         return 0;
@@ -701,12 +723,7 @@ template <typename T> struct Engine : IEngine {
         for (;;) {
             for (int b = 0; b < burst; ++b) {
                 if (cg_graph) HIP_OK(hipGraphLaunch(cg_graph, stream));
-                else if (amg_on) for (int j = 0; j < ch; ++j) launch_iteration(j & 1);
-                else for (int j = 0; j < ch; ++j) {
-                    launch_matvec(j & 1);
-                    if (int rc = allreduce(sbuf, (size_t)pr.P * 3 + nbP)) return rc;
-                    launch_cg_update(j & 1);
-                }
+                else for (int j = 0; j < ch; ++j) if (int rc = launch_iteration(j & 1)) return rc;
                 launched += ch;
             }
             if (timing) std::fprintf(stderr, "[tsgo] solve: %d chunk(s) enqueued at %.0f us", burst, since());
@@ -722,8 +739,9 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
 
-    // landmarks: dl = u - Dl^-1 W^T x (+ optional update); poses: update; returns ||delta||
-    int do_backsub_update(T step, double* delta_norm) {
+    // landmarks: dl = u - Dl^-1 W^T x (+ optional update); poses: update.  Returns ||delta_p||^2 (identical on every
+    // rank: pose vectors are replicated) and THIS rank's ||delta_l||^2 (landmark deltas are shard-local).
+    int do_backsub_update(T step, double* np2_out, double* nl2_local_out) {
         const int P = pr.P;
         hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, zc, xprev, (const T*)nullptr, T(0));
         have_prev = step != T(0);     // a probe (step 0) leaves nothing to carry over
@@ -735,16 +753,21 @@ template <typename T> struct Engine : IEngine {
         double np2 = 0, nl2 = 0;
         for (int k = 0; k < nbC; ++k) np2 += (double)h_scratch[k];
         for (int k = 0; k < nl; ++k) nl2 += (double)h_scratch[nbC + k];
-        if (collective()) {      // landmark deltas are shard-local
-            T* d = part;          // reuse as a one-element device scratch
-            T v = (T)nl2;
-            HIP_OK(hipMemcpyAsync(d, &v, sizeof(T), hipMemcpyHostToDevice, stream));
-            if (int rc = allreduce(d, 1)) return rc;
-            HIP_OK(hipMemcpyAsync(&v, d, sizeof(T), hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipStreamSynchronize(stream));
-            nl2 = (double)v;
-        }
-        *delta_norm = std::sqrt(np2 + nl2);
+        *np2_out = np2; *nl2_local_out = nl2;
+        return 0;
+    }
+    // Sum of the ranks' landmark-delta norms.  The stop rule ||delta|| < 1e-3 (OptimizerCpu.h:173) can only fire when the
+    // pose part alone is already below the tolerance, and the pose part is known on every rank: this collective runs
+    // when that happens and once at the end of tsgo_optimize for the reported norm, not once per iteration.
+    int landmark_norm_allreduce(double* nl2) {
+        if (!collective()) return 0;
+        T* d = npart;         // one-element device scratch (its partials were consumed by do_backsub_update)
+        T v = (T)*nl2;
+        HIP_OK(hipMemcpyAsync(d, &v, sizeof(T), hipMemcpyHostToDevice, stream));
+        if (int rc = allreduce(d, 1)) return rc;
+        HIP_OK(hipMemcpyAsync(&v, d, sizeof(T), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        *nl2 = (double)v;
         return 0;
     }
 
@@ -755,6 +778,8 @@ template <typename T> struct Engine : IEngine {
         s.n_pose = pr.P; s.n_lm = pr.L_total; s.n_odom_edges = pr.n_odom_edges_total; s.n_lm_edges = pr.n_lm_edges_total;
         s.ms_setup = ms_setup;
         double prevErr = -1; int penalty = 0;
+        bool nl2_whole = true;        // sharded: last_delta_norm holds every rank's landmark part (see landmark_norm_allreduce)
+        double np2_last = 0, nl2_last = 0;
         const int fallbacks0 = n_fallbacks;
         s.stop_reason = TSGO_STOP_CAP;
         const auto wall0 = std::chrono::steady_clock::now();
@@ -764,7 +789,8 @@ template <typename T> struct Engine : IEngine {
             if (int rc = do_linearize(&err)) return rc;
             HIP_OK(hipEventRecord(ev[1], stream));
             if (it < TSGO_MAX_TRACE) s.chi2[it] = err;
-            s.iterations_run = it + 1;
+            s.chi2_last = err;
+            s.iterations_run = it + 1; s.trace_len = std::min(it + 1, TSGO_MAX_TRACE);
             if (prevErr > 0 && err > prevErr) {                          // OptimizerCpu.h:140-153
                 if (++penalty > 2) { s.stop_reason = TSGO_STOP_WORSE; break; }
             } else penalty = 0;
@@ -774,17 +800,29 @@ template <typename T> struct Engine : IEngine {
             if (it < TSGO_MAX_TRACE) s.pcg_iters[it] = cg;
             s.pcg_iters_total += cg;
             if (fail == 1) { s.stop_reason = TSGO_STOP_SOLVER; break; }
-            double nrm = 0;
-            if (int rc = do_backsub_update((T)kStepScale, &nrm)) return rc;   // :159-165
+            double np2 = 0, nl2 = 0;
+            if (int rc = do_backsub_update((T)kStepScale, &np2, &nl2)) return rc;   // :159-165
             HIP_OK(hipEventRecord(ev[3], stream));
             HIP_OK(hipEventSynchronize(ev[3]));
             HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[1])); s.ms_linearize += ms;
             HIP_OK(hipEventElapsedTime(&ms, ev[1], ev[2])); s.ms_solve += ms;
             HIP_OK(hipEventElapsedTime(&ms, ev[2], ev[3])); s.ms_update += ms;
-            s.last_delta_norm = nrm;
-            if (std::fabs(err - prevErr) < kPlateauTol) { s.stop_reason = TSGO_STOP_PLATEAU; break; }   // :167-171
-            if (nrm < kDeltaTol) { s.stop_reason = TSGO_STOP_CONVERGED; break; }                        // :173-177
+            nl2_whole = !collective();
+            const bool last = it + 1 == iterations;
+            const bool plateau = std::fabs(err - prevErr) < kPlateauTol;
+            if (collective() && (last || plateau || np2 < kDeltaTol * kDeltaTol)) {      // every rank takes this branch or none does
+                if (int rc = landmark_norm_allreduce(&nl2)) return rc;
+                nl2_whole = true;
+            }
+            s.last_delta_norm = std::sqrt(np2 + nl2);
+            np2_last = np2; nl2_last = nl2;
+            if (plateau) { s.stop_reason = TSGO_STOP_PLATEAU; break; }                                  // :167-171
+            if (nl2_whole && s.last_delta_norm < kDeltaTol) { s.stop_reason = TSGO_STOP_CONVERGED; break; }   // :173-177
             prevErr = err;                                                                              // :179
+        }
+        if (!nl2_whole) {             // the loop ended before its last update's landmark norm was summed (worse / solver stop)
+            if (int rc = landmark_norm_allreduce(&nl2_last)) return rc;
+            s.last_delta_norm = std::sqrt(np2_last + nl2_last);
         }
         s.pcg_fallbacks = n_fallbacks - fallbacks0;
         s.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -846,8 +884,8 @@ template <typename T> struct Engine : IEngine {
         if (int rc = do_solve(&cg, &fail)) return rc;
         if (iters) *iters = cg;
         // back-substitute with step 0: state untouched (theta is re-derived from the same cos/sin)
-        double nrm = 0;
-        if (int rc = do_backsub_update((T)0, &nrm)) return rc;
+        double np2 = 0, nl2 = 0;
+        if (int rc = do_backsub_update((T)0, &np2, &nl2)) return rc;
         const int P = pr.P, L = pr.L;
         std::vector<T> hx((size_t)P * 3), hd((size_t)std::max(L, 1) * 2);
         { if (int rc_ = copy_sync(hx.data(), x, hx.size() * sizeof(T), hipMemcpyDeviceToHost)) return rc_; }
@@ -890,8 +928,8 @@ template <typename T> struct Engine : IEngine {
                     }
                     case 3: if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv); break;
                     case 4: LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18); break;
-                    case 6: if (amg_on) launch_amg_setup(); break;
-                    default: launch_iteration(0); launch_iteration(1); break;
+                    case 6: if (amg_on) { if (int rc = launch_amg_setup()) return rc; } break;
+                    default: if (int rc = launch_iteration(0)) return rc; if (int rc = launch_iteration(1)) return rc; break;
                 }
             }
             HIP_OK(hipEventRecord(ev[1], stream));

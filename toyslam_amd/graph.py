@@ -62,39 +62,64 @@ class EdgeLandmark2d(_Edge):
 
 
 class OptGraph:
-    """python/optimizer/opt_graph.py:1-31 (same methods, same RuntimeError on unknown ids)."""
+    """Container the optimizers consume: id -> vertex (insertion-ordered), a list of edges, the set of gauge-fixed ids.
 
-    def __init__(self):
-        self.vertices = {}
-        self.edges = []
-        self.fixed_vertices = set()
+    Interface-compatible with the reference's python/optimizer/opt_graph.py (the accessor names are what
+    graph_to_bytes.py:43-64 and slam_main.py:157-211 call); the body is this package's own.  Unknown ids raise
+    KeyError-derived UnknownVertex (a RuntimeError too, which is what the reference's callers catch)."""
 
+    class UnknownVertex(KeyError, RuntimeError):
+        def __str__(self):
+            return "vertex id %r is not in the graph" % (self.args[0],)
+
+    __slots__ = ("_v", "_e", "_fixed")
+
+    def __init__(self, vertices=None, edges=(), fixed=()):
+        self._v = dict(vertices or {})
+        self._e = list(edges)
+        self._fixed = set()
+        for i in fixed:
+            self.fix_vertex(i)
+
+    def _known(self, vid):
+        try:
+            return self._v[vid]
+        except KeyError:
+            raise OptGraph.UnknownVertex(vid) from None
+
+    # ---- building ----
     def add_vertex(self, id, vertex, fixed=False):
-        self.vertices[id] = vertex
+        self._v[id] = vertex
         if fixed:
-            self.fix_vertex(id)
-
-    def fix_vertex(self, id):
-        if id not in self.vertices:
-            raise RuntimeError("Fix LM: {} is not found".format(id))
-        self.fixed_vertices.add(id)
+            self._fixed.add(id)
 
     def add_edge(self, edge):
-        self.edges.append(edge)
+        self._e.append(edge)
 
+    def fix_vertex(self, id):
+        self._known(id)
+        self._fixed.add(id)
+
+    # ---- reading ----
     def get_vertex(self, id):
-        if id not in self.vertices:
-            raise RuntimeError("get_position() {} is not found".format(id))
-        return self.vertices[id]
+        return self._known(id)
 
     def get_vertices(self):
-        return self.vertices
+        return self._v
 
     def get_edges(self):
-        return self.edges
+        return self._e
 
     def get_fixed_vertices(self):
-        return self.fixed_vertices
+        return self._fixed
+
+    # attribute spellings some callers of the reference use directly
+    vertices = property(get_vertices)
+    edges = property(get_edges)
+    fixed_vertices = property(get_fixed_vertices)
+
+    def __len__(self):
+        return len(self._v)
 
 
 class tsgo_graph(C.Structure):

@@ -23,7 +23,7 @@ class HipOptimizer:
         cfg.device, cfg.precision, cfg.pcg_rel_tol, cfg.pcg_max_iters = device, precision, pcg_rel_tol, pcg_max_iters
         cfg.lanes_per_pose, cfg.lanes_per_lm, cfg.use_graphs = lanes_per_pose, lanes_per_lm, int(use_graphs)
         cfg.rank, cfg.world = rank, world
-        cfg.preconditioner = {"jacobi": 0, "amg": 1}[preconditioner] if world == 1 else 0
+        cfg.preconditioner = {"jacobi": 0, "amg": 1}[preconditioner]
         if xcd_map is not None:
             cfg.xcd_map = int(xcd_map)
         if warm_start is not None:
@@ -52,8 +52,8 @@ class HipOptimizer:
     def optimize(self, iterations):
         st = _lib.tsgo_stats()
         _lib.check(self.lib, self.lib.tsgo_optimize(self.h, iterations, C.byref(st)), "tsgo_optimize")
-        n = min(st.iterations_run, _lib.TSGO_MAX_TRACE)
-        return dict(iters=st.iterations_run, stop=STOP[st.stop_reason], chi2=np.array(st.chi2[:n]),
+        n = st.trace_len
+        return dict(iters=st.iterations_run, stop=STOP[st.stop_reason], chi2=np.array(st.chi2[:n]), chi2_last=st.chi2_last,
                     cg_iters=np.array(st.pcg_iters[:n]), delta_norm=st.last_delta_norm, ms_total=st.ms_total,
                     ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup,
                     n_pose=st.n_pose, n_lm=st.n_lm, n_odom_edges=st.n_odom_edges, n_lm_edges=st.n_lm_edges,

@@ -128,6 +128,18 @@ int tsgo_comm_init(tsgo_optimizer* opt, const uint8_t id[128]);
  * (preconditioner application included), 6 the multigrid numeric setup of one GN iteration. */
 int tsgo_time_kernel(tsgo_optimizer* opt, int32_t which, int32_t reps, double* us_per_launch, double* bytes_per_launch);
 
+/* Timing probe for the multigrid V-cycle's coarse levels (bench.py's per-kernel table): for every explicit level below
+ * level 0, the average time of one block-Jacobi smoothing sweep (k_bcsr_residual, hipEvent over `reps` back-to-back
+ * launches), its algorithmic bytes (the level's 3x3 blocks + column indices once, three vectors and the diagonal
+ * inverse) and how many such sweeps one V-cycle runs on that level.  Returns the number of levels written (<= cap). */
+typedef struct tsgo_cycle_level {
+    int64_t rows, blocks;            /* block rows / 3x3 blocks of the level's matrix */
+    int32_t sweeps_per_cycle;        /* k_bcsr_residual launches per V-cycle on this level (smoothing + residual) */
+    int32_t lanes_per_row;
+    double us_per_sweep, bytes_per_sweep;
+} tsgo_cycle_level;
+int tsgo_cycle_probe(tsgo_optimizer* opt, int32_t reps, tsgo_cycle_level* out, int32_t cap);
+
 const char* tsgo_last_error(void);
 
 /* ---- host-only: wire codec (libtsgo_host.so and libtsgo_hip.so) ---------------------------------
@@ -183,6 +195,10 @@ typedef struct tsgo_amg_info {
     int32_t agg_min[8], agg_max[8]; /* smallest / largest aggregate (in nodes of that level) leaving each level */
 } tsgo_amg_info;
 int tsgo_amg_probe(const tsgo_graph* g, tsgo_amg_info* out);
+/* The same for shard `rank` of `world` (edge-sharded runs replicate the hierarchy; only the level-0 contribution lists
+ * are per shard): out->schur_contribs = landmark-pair terms THIS shard sums, *odom_contribs_out = its odometry terms.
+ * Over all ranks both add up to the unsharded counts. */
+int tsgo_amg_probe_shard(const tsgo_graph* g, int32_t rank, int32_t world, tsgo_amg_info* out, int64_t* odom_contribs_out);
 
 #ifdef __cplusplus
 }

@@ -223,3 +223,22 @@ def test_hub_landmark_keeps_the_multigrid_lists_bounded_and_the_answer_exact():
     d_ref, err, _, _ = util.dense_solution(g2)
     r = oracle.sparse_step(util.to_oracle(g2), 1e-12, precond="amg")
     assert np.abs(r["delta"] - d_ref).max() <= 1e-8 * np.abs(d_ref).max()
+
+
+@pytest.mark.parametrize("world", [2, 3, 8])
+def test_sharded_multigrid_lists_partition_the_whole_graphs_lists(world):
+    """Edge-sharded runs replicate the hierarchy and split only the level-0 contribution lists (host/amg.cpp:
+    build_amg_sharded): same levels on every rank, and every landmark-pair / odometry term is summed by exactly one rank."""
+    lib = _lib.host_lib()
+    g = synth.make(3000, 10, loop_closures=40, seed=4)
+    cg = g.c_struct()
+    whole = _lib.tsgo_amg_info(); od_whole = C.c_int64()
+    _lib.check(lib, lib.tsgo_amg_probe_shard(C.byref(cg), 0, 1, C.byref(whole), C.byref(od_whole)), "tsgo_amg_probe_shard")
+    pairs = odoms = 0
+    for rank in range(world):
+        info = _lib.tsgo_amg_info(); od = C.c_int64()
+        _lib.check(lib, lib.tsgo_amg_probe_shard(C.byref(cg), rank, world, C.byref(info), C.byref(od)), "tsgo_amg_probe_shard")
+        assert info.n_levels == whole.n_levels
+        assert list(info.rows) == list(whole.rows) and list(info.blocks) == list(whole.blocks) and list(info.p_blocks) == list(whole.p_blocks)
+        pairs += info.schur_contribs; odoms += od.value
+    assert pairs == whole.schur_contribs and odoms == od_whole.value and pairs > 0 and odoms > 0

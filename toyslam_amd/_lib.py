@@ -24,6 +24,11 @@ class tsgo_stats(C.Structure):
                 ("pcg_fallbacks", C.c_int32), ("trace_len", C.c_int32), ("chi2_last", C.c_double)]
 
 
+class tsgo_cycle_level(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("blocks", C.c_int64), ("sweeps_per_cycle", C.c_int32), ("lanes_per_row", C.c_int32),
+                ("us_per_sweep", C.c_double), ("bytes_per_sweep", C.c_double)]
+
+
 class tsgo_synth_config(C.Structure):
     _fields_ = [("n_poses", C.c_int64), ("lm_per_pose", C.c_int32), ("lm_obs_target", C.c_double),
                 ("loop_closures", C.c_int32), ("seed", C.c_uint64)]
@@ -44,9 +49,9 @@ class tsgo_amg_info(C.Structure):
 
 HOST_SYMBOLS = ["tsgo_default_config", "tsgo_last_error", "tsgo_wire_decode", "tsgo_wire_view", "tsgo_wire_free",
                 "tsgo_wire_encode_response", "tsgo_wire_encode_request", "tsgo_synth_create", "tsgo_synth_view",
-                "tsgo_synth_truth", "tsgo_synth_free", "tsgo_layout_probe", "tsgo_amg_probe"]
+                "tsgo_synth_truth", "tsgo_synth_free", "tsgo_layout_probe", "tsgo_amg_probe", "tsgo_amg_probe_shard"]
 DEVICE_SYMBOLS = ["tsgo_create", "tsgo_destroy", "tsgo_set_graph", "tsgo_optimize", "tsgo_get_vertices",
-                  "tsgo_linearize", "tsgo_solve_step", "tsgo_comm_unique_id", "tsgo_comm_init", "tsgo_time_kernel"]
+                  "tsgo_linearize", "tsgo_solve_step", "tsgo_comm_unique_id", "tsgo_comm_init", "tsgo_time_kernel", "tsgo_cycle_probe"]
 
 
 def _declare_host(L):
@@ -65,6 +70,7 @@ def _declare_host(L):
     L.tsgo_layout_probe.argtypes = [C.POINTER(tsgo_graph), C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                     C.POINTER(tsgo_layout_info)]
     L.tsgo_amg_probe.argtypes = [C.POINTER(tsgo_graph), C.POINTER(tsgo_amg_info)]
+    L.tsgo_amg_probe_shard.argtypes = [C.POINTER(tsgo_graph), C.c_int32, C.c_int32, C.POINTER(tsgo_amg_info), C.POINTER(C.c_int64)]
     del u8p
 
 
@@ -80,6 +86,7 @@ def _declare_device(L):
     L.tsgo_comm_unique_id.argtypes = [vp]
     L.tsgo_comm_init.argtypes = [vp, vp]
     L.tsgo_time_kernel.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.tsgo_cycle_probe.argtypes = [vp, C.c_int32, C.POINTER(tsgo_cycle_level), C.c_int32]
 
 
 _host = None

@@ -29,16 +29,15 @@ extern "C" int tsgo_layout_probe(const tsgo_graph* g, int32_t rank, int32_t worl
     return 0;
 }
 
-extern "C" int tsgo_amg_probe(const tsgo_graph* g, tsgo_amg_info* out) {
-    if (!g || !out) return tsgo::set_error(-1, "tsgo_amg_probe: null argument");
+static int amg_probe(const tsgo_graph* g, int rank, int world, tsgo_amg_info* out, int64_t* odom_out) {
     std::memset(out, 0, sizeof(*out));
-    tsgo::Problem pr; tsgo::BuildOptions bo;
+    tsgo::Problem pr; tsgo::BuildOptions bo; bo.rank = rank; bo.world = world;
     auto t0 = std::chrono::steady_clock::now();
     std::string err = tsgo::build_problem(*g, bo, pr);
     if (!err.empty()) return tsgo::set_error(-2, err);
     auto t1 = std::chrono::steady_clock::now();
     tsgo::AmgSym amg;
-    err = tsgo::build_amg(pr, amg);
+    err = world > 1 ? tsgo::build_amg_sharded(*g, pr, amg) : tsgo::build_amg(pr, amg);
     if (!err.empty()) return tsgo::set_error(-2, err);
     auto t2 = std::chrono::steady_clock::now();
     out->ms_layout = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -55,5 +54,16 @@ extern "C" int tsgo_amg_probe(const tsgo_graph* g, tsgo_amg_info* out) {
     if (n < 8) { out->rows[n] = amg.A_last.n_rows; out->blocks[n] = amg.A_last.nnz(); ++n; }
     out->n_levels = n;
     out->schur_contribs = (int64_t)amg.schur.slot_i.size();
+    if (odom_out) *odom_out = (int64_t)amg.schur.od_slot.size();
     return 0;
+}
+
+extern "C" int tsgo_amg_probe(const tsgo_graph* g, tsgo_amg_info* out) {
+    if (!g || !out) return tsgo::set_error(-1, "tsgo_amg_probe: null argument");
+    return amg_probe(g, 0, 1, out, nullptr);
+}
+
+extern "C" int tsgo_amg_probe_shard(const tsgo_graph* g, int32_t rank, int32_t world, tsgo_amg_info* out, int64_t* odom_contribs_out) {
+    if (!g || !out || world < 1 || rank < 0 || rank >= world) return tsgo::set_error(-1, "tsgo_amg_probe_shard: bad argument");
+    return amg_probe(g, rank, world, out, odom_contribs_out);
 }

@@ -88,6 +88,7 @@ struct IEngine {
     virtual int linearize(double* diag, double* grad, double* chi2) = 0;
     virtual int solve_step(double* delta, double* chi2, int* iters) = 0;
     virtual int time_kernel(int which, int reps, double* us, double* bytes) = 0;
+    virtual int cycle_probe(int reps, tsgo_cycle_level* out, int cap) = 0;
     ncclComm_t comm = nullptr;
 };
 
@@ -896,6 +897,32 @@ template <typename T> struct Engine : IEngine {
         return fail == 1 ? set_error(-21, "PCG breakdown") : 0;
     }
 
+    int cycle_probe(int reps, tsgo_cycle_level* out, int cap) override {
+        if (!have_graph_data) return set_error(-3, "tsgo_cycle_probe: no graph set");
+        HIP_OK(hipSetDevice(cfg.device));
+        if (!amg_on) return 0;
+        double chi2;
+        if (int rc = do_linearize(&chi2)) return rc;      // a built hierarchy; state slot 0 says "not done"
+        int n = 0;
+        for (size_t l = 1; l < lv.size() && n < cap; ++l, ++n) {
+            DevLevel<T>& L = lv[l];
+            const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
+            for (int pass = 0; pass < 2; ++pass) {
+                const int m = pass == 0 ? 3 : reps;
+                HIP_OK(hipEventRecord(ev[0], stream));
+                for (int k = 0; k < m; ++k)
+                    LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)L.r, (const T*)L.z, (const H*)L.Dinv, L.z2, (const T*)(omega_dev + l), (const CgState<T>*)st[0]);
+                HIP_OK(hipEventRecord(ev[1], stream));
+                HIP_OK(hipEventSynchronize(ev[1]));
+                if (pass == 1) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[1])); out[n].us_per_sweep = 1e3 * ms / m; }
+            }
+            out[n].rows = L.n; out[n].blocks = L.nnzA; out[n].lanes_per_row = lprA;
+            out[n].sweeps_per_cycle = 2 * nu_at(l);         // (nu - 1) pre-sweeps + the residual + nu post-sweeps
+            out[n].bytes_per_sweep = (double)L.nnzA * (9 * sizeof(H) + 4) + (double)L.n * (3 * 3 * sizeof(T) + 9 * sizeof(H) + 4);
+        }
+        return n;
+    }
+
     // which: 0 schur_lm, 1 schur_pose, 2 cg_update, 3 lin_lm, 4 lin_pose, 5 one whole PCG iteration
     int time_kernel(int which, int reps, double* us, double* bytes) override {
         if (!have_graph_data) return set_error(-3, "tsgo_time_kernel: no graph set");
@@ -1010,6 +1037,10 @@ int tsgo_solve_step(tsgo_optimizer* o, double* delta, double* chi2, int32_t* ite
 int tsgo_time_kernel(tsgo_optimizer* o, int32_t which, int32_t reps, double* us, double* bytes) {
     if (!o || !us || !bytes || reps <= 0) return tsgo::set_error(-1, "tsgo_time_kernel: bad argument");
     return o->eng->time_kernel(which, reps, us, bytes);
+}
+int tsgo_cycle_probe(tsgo_optimizer* o, int32_t reps, tsgo_cycle_level* out, int32_t cap) {
+    if (!o || !out || reps <= 0 || cap <= 0) return tsgo::set_error(-1, "tsgo_cycle_probe: bad argument");
+    return o->eng->cycle_probe(reps, out, cap);
 }
 int tsgo_comm_unique_id(uint8_t id_out[128]) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");

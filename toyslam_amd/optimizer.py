@@ -82,6 +82,13 @@ class HipOptimizer:
                    "tsgo_time_kernel")
         return us.value, nbytes.value
 
+    def level_sweep_times(self, reps=100):
+        """Per coarse level of the V-cycle: (us per smoothing sweep, algorithmic bytes per sweep, sweeps per cycle)."""
+        arr = (_lib.tsgo_cycle_level * 16)()
+        n = self.lib.tsgo_cycle_probe(self.h, reps, arr, 16)
+        _lib.check(self.lib, min(n, 0), "tsgo_cycle_probe")
+        return [(arr[k].us_per_sweep, arr[k].bytes_per_sweep, arr[k].sweeps_per_cycle) for k in range(n)]
+
     def comm_unique_id(self):
         buf = (C.c_uint8 * 128)()
         _lib.check(self.lib, self.lib.tsgo_comm_unique_id(buf), "tsgo_comm_unique_id")

@@ -64,6 +64,9 @@ typedef struct tsgo_config {
     int32_t xcd_map;         /* 1: workgroup -> slice map gives each XCD a contiguous eighth of the vertices; 0: round-robin */
     int32_t warm_start;      /* 1 (default): PCG starts from (1 - step) * the previous Gauss-Newton iteration's pose delta
                                 (the un-taken remainder of the last step); 0: from zero.  Same answer to pcg_rel_tol. */
+    int32_t reuse_structure; /* 1 (default): tsgo_set_graph with the SAME vertex ids/types, edge list and fixed list as the graph the
+                                handle already holds only refills estimates, measurements and weights (the reference re-creates
+                                everything per message, remote/app/ConnectionHandler.h:18-21); 0: always rebuild.  Same results. */
 } tsgo_config;
 
 enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_CONVERGED = 3, TSGO_STOP_SOLVER = 4 };
@@ -76,7 +79,9 @@ typedef struct tsgo_stats {
     int32_t pcg_iters[TSGO_MAX_TRACE];   /* PCG iterations of each solve */
     double last_delta_norm;              /* ||delta||_2 of the last solve (unscaled, :173) */
     double ms_total, ms_linearize, ms_solve, ms_update;   /* device time, hipEvent */
-    double ms_setup;                     /* host layout build + upload in tsgo_set_graph */
+    double ms_setup;                     /* tsgo_set_graph: host layout build + upload, or the refill when the structure was reused */
+    int32_t structure_reused;            /* 1 when the last tsgo_set_graph found the same structure and only refilled values */
+    int32_t reserved;
     int64_t n_pose, n_lm, n_odom_edges, n_lm_edges;
     int64_t pcg_iters_total;
     int32_t pcg_fallbacks;               /* solves repeated with block-Jacobi after a multigrid breakdown */
@@ -149,6 +154,11 @@ const char* tsgo_last_error(void);
  * (WITH the u32 length prefix) and python/remote/bytes_to_graph.py:49-108 reads. */
 typedef struct tsgo_wire_graph tsgo_wire_graph;
 int tsgo_wire_decode(const uint8_t* payload, size_t len, tsgo_wire_graph** out);
+/* The same into an existing handle (tsgo_wire_new, or one decoded before): its arrays keep their capacity, so a
+ * connection that sends graph after graph (remote/app/ConnectionHandler.h:30-32) does not fault in ~2x the payload of
+ * fresh pages per message.  On failure the handle stays valid but holds no graph. */
+tsgo_wire_graph* tsgo_wire_new(void);
+int tsgo_wire_decode_into(tsgo_wire_graph* w, const uint8_t* payload, size_t len);
 void tsgo_wire_view(const tsgo_wire_graph* w, tsgo_graph* view);
 /* Encodes the reply for the decoded request with vertex positions replaced by v_pos (3 doubles per
  * vertex, request order).  Two-call pattern: buf = NULL returns the size. */

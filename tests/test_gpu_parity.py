@@ -194,6 +194,57 @@ def test_collective_path_at_config_2_size_keeps_multigrid_iteration_counts():
     assert util.max_vertex_diff(vb, ref["v_pos"], g.v_type) < 1e-7
 
 
+@pytest.mark.parametrize("precond,precision", [("amg", 64), ("jacobi", 64), ("amg", 32)])
+def test_same_structure_again_only_refills_values_and_equals_a_fresh_engine(precond, precision):
+    """tsgo_set_graph with the structure the handle already holds (same ids, types, edges, fixed list) keeps
+    layout, multigrid patterns, tables and the captured hipGraph, and refills estimates, measurements and weights — and
+    gives, bit for bit, what a fresh engine gives for that graph.  A different structure rebuilds everything."""
+    g = synth.make(3000, 10, loop_closures=20, seed=9)
+    rng = np.random.default_rng(1)
+    g2 = g.copy()
+    g2.v_pos[:, :2] += rng.normal(0, 0.05, size=(len(g.v_id), 2))
+    g2.v_pos[g.v_type == 0, 2] += rng.normal(0, 0.01, size=int((g.v_type == 0).sum()))
+    lm = g.e_type == 1
+    g2.e_meas[lm, 0] *= 1.01; g2.e_meas[lm, 1] += 0.002
+    g2.e_inf[:] = g.e_inf * 0.75
+    tol = 1e-10 if precision == 64 else 1e-5
+    fresh = HipOptimizer(pcg_rel_tol=tol, preconditioner=precond, precision=precision, reuse_structure=False)
+    try:
+        fresh.set_graph(g2); rf = fresh.optimize(5); vf = fresh.vertices()
+        assert not rf["structure_reused"]
+        fresh.set_graph(g2); rf2 = fresh.optimize(5)               # reuse switched off: rebuilt, same answer
+        assert not rf2["structure_reused"]
+        np.testing.assert_array_equal(rf["chi2"], rf2["chi2"])
+    finally:
+        fresh.close()
+    o = HipOptimizer(pcg_rel_tol=tol, preconditioner=precond, precision=precision)
+    try:
+        o.set_graph(g); r0 = o.optimize(3)
+        assert not r0["structure_reused"]
+        o.set_graph(g2); r = o.optimize(5); v = o.vertices()
+        assert r["structure_reused"] and r["ms_setup"] < r0["ms_setup"]
+        np.testing.assert_array_equal(r["chi2"], rf["chi2"])         # no atomics, same tables, same patterns: same bits
+        np.testing.assert_array_equal(r["cg_iters"], rf["cg_iters"])
+        np.testing.assert_array_equal(v, vf)
+        grown = synth.make(3150, 10, loop_closures=20, seed=9)     # a new structure: rebuilt, and correct
+        o.set_graph(grown); r3 = o.optimize(3); v3 = o.vertices()
+        assert not r3["structure_reused"]
+        if precision == 64:
+            ref = oracle.sparse_optimize(util.to_oracle(grown), 3, pcg_tol=1e-12, precond="jacobi" if precond == "amg" else "amg")
+            np.testing.assert_allclose(r3["chi2"], ref["chi2"], rtol=1e-8)
+            assert util.max_vertex_diff(v3, ref["v_pos"], grown.v_type) < 1e-6
+        # a singular ODOM measurement arriving in a refill: reported, and the handle holds no graph afterwards
+        o.set_graph(grown)
+        bad_grown = grown.copy(); bad_grown.e_meas[np.where(grown.e_type == 0)[0][0]] = 0
+        with pytest.raises(RuntimeError, match="singular"):
+            o.set_graph(bad_grown)
+        o.set_graph(g2); r4 = o.optimize(5)                         # the handle recovers with a full rebuild
+        assert not r4["structure_reused"]
+        np.testing.assert_array_equal(r4["chi2"], rf["chi2"])
+    finally:
+        o.close()
+
+
 def test_bench_tolerance_meets_the_north_star_bar():
     """bench.py runs PCG at rel tol 1e-10 (1e-8 leaves 1.5e-6 on config-2 poses): final chi^2 (relative) and poses (absolute) stay within 1e-6 of
     the dense cpu/eigen restatement on config 1 and of the tightly converged twin on config 2."""

@@ -137,3 +137,29 @@ def test_requests_from_several_connections_run_concurrently_and_stay_correct(ser
     for k in range(3):
         assert outs[k] is not None and len(outs[k].v_id) == len(graphs[k].v_id)
         assert util.max_vertex_diff(outs[k].v_pos, refs[k]["v_pos"], graphs[k].v_type) < 2e-4    # f32 on the wire
+
+
+def test_same_structure_then_a_grown_graph_on_one_connection(server):
+    """SURVEY 8f rank 2.  What a SLAM front-end does over one connection: send a graph, send the SAME structure again with
+    the estimates that came back (the server refills values and keeps layout, patterns and tables), then a graph grown by
+    5 % (new structure: everything is rebuilt).  Every reply is checked against the dense cpu/eigen restatement of ITS
+    request; the server's log says which path each request took."""
+    from toyslam_amd import synth
+    from toyslam_amd.graph import GraphArrays
+    port, proc = server
+    g0 = synth.make(120, 8, seed=21).rounded_to_wire()
+    grown = synth.make(126, 8, seed=21).rounded_to_wire()
+    with socket.create_connection(("127.0.0.1", port)) as s:
+        ref0 = oracle.optimize(util.to_oracle(g0), 50, mode="cpp", solver="chol")
+        v0 = remote.bytes_to_vertices(_roundtrip(s, remote.graph_to_bytes(g0)), g0)
+        assert util.max_vertex_diff(v0, ref0["v_pos"], g0.v_type) < 1e-5
+        # the same structure, estimates replaced by the (f32) reply, measurements re-weighted
+        g1 = GraphArrays(g0.v_id, g0.v_type, v0, g0.e_type, g0.e_ids, g0.e_meas, (g0.e_inf * 0.5).astype(np.float32).astype(np.float64), g0.fixed)
+        ref1 = oracle.optimize(util.to_oracle(g1), 50, mode="cpp", solver="chol")
+        v1 = remote.bytes_to_vertices(_roundtrip(s, remote.graph_to_bytes(g1)), g1)
+        assert util.max_vertex_diff(v1, ref1["v_pos"], g1.v_type) < 1e-5
+        assert util.max_vertex_diff(v1, v0, g1.v_type) > 1e-4          # it did move: the second request was really optimised
+        ref2 = oracle.optimize(util.to_oracle(grown), 50, mode="cpp", solver="chol")
+        v2 = remote.bytes_to_vertices(_roundtrip(s, remote.graph_to_bytes(grown)), grown)
+        assert util.max_vertex_diff(v2, ref2["v_pos"], grown.v_type) < 1e-5
+    assert proc.poll() is None

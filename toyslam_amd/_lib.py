@@ -12,14 +12,14 @@ class tsgo_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("pcg_rel_tol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("lanes_per_pose", C.c_int32), ("lanes_per_lm", C.c_int32),
                 ("use_graphs", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("verbose", C.c_int32),
-                ("preconditioner", C.c_int32), ("xcd_map", C.c_int32), ("warm_start", C.c_int32)]
+                ("preconditioner", C.c_int32), ("xcd_map", C.c_int32), ("warm_start", C.c_int32), ("reuse_structure", C.c_int32)]
 
 
 class tsgo_stats(C.Structure):
     _fields_ = [("iterations_run", C.c_int32), ("stop_reason", C.c_int32), ("chi2", C.c_double * TSGO_MAX_TRACE),
                 ("pcg_iters", C.c_int32 * TSGO_MAX_TRACE), ("last_delta_norm", C.c_double),
                 ("ms_total", C.c_double), ("ms_linearize", C.c_double), ("ms_solve", C.c_double),
-                ("ms_update", C.c_double), ("ms_setup", C.c_double), ("n_pose", C.c_int64), ("n_lm", C.c_int64),
+                ("ms_update", C.c_double), ("ms_setup", C.c_double), ("structure_reused", C.c_int32), ("reserved", C.c_int32), ("n_pose", C.c_int64), ("n_lm", C.c_int64),
                 ("n_odom_edges", C.c_int64), ("n_lm_edges", C.c_int64), ("pcg_iters_total", C.c_int64),
                 ("pcg_fallbacks", C.c_int32), ("trace_len", C.c_int32), ("chi2_last", C.c_double)]
 
@@ -47,7 +47,7 @@ class tsgo_amg_info(C.Structure):
                 ("agg_min", C.c_int32 * 8), ("agg_max", C.c_int32 * 8)]
 
 
-HOST_SYMBOLS = ["tsgo_default_config", "tsgo_last_error", "tsgo_wire_decode", "tsgo_wire_view", "tsgo_wire_free",
+HOST_SYMBOLS = ["tsgo_default_config", "tsgo_last_error", "tsgo_wire_decode", "tsgo_wire_new", "tsgo_wire_decode_into", "tsgo_wire_view", "tsgo_wire_free",
                 "tsgo_wire_encode_response", "tsgo_wire_encode_request", "tsgo_synth_create", "tsgo_synth_view",
                 "tsgo_synth_truth", "tsgo_synth_free", "tsgo_layout_probe", "tsgo_amg_probe", "tsgo_amg_probe_shard"]
 DEVICE_SYMBOLS = ["tsgo_create", "tsgo_destroy", "tsgo_set_graph", "tsgo_optimize", "tsgo_get_vertices",
@@ -59,6 +59,8 @@ def _declare_host(L):
     L.tsgo_default_config.argtypes = [C.POINTER(tsgo_config)]; L.tsgo_default_config.restype = None
     L.tsgo_last_error.restype = C.c_char_p
     L.tsgo_wire_decode.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(vp)]
+    L.tsgo_wire_new.argtypes = []; L.tsgo_wire_new.restype = vp
+    L.tsgo_wire_decode_into.argtypes = [vp, C.c_char_p, C.c_size_t]
     L.tsgo_wire_view.argtypes = [vp, C.POINTER(tsgo_graph)]; L.tsgo_wire_view.restype = None
     L.tsgo_wire_free.argtypes = [vp]; L.tsgo_wire_free.restype = None
     L.tsgo_wire_encode_response.argtypes = [vp, vp, vp, C.c_size_t]; L.tsgo_wire_encode_response.restype = C.c_int64

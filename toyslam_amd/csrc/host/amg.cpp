@@ -1,5 +1,6 @@
 // amg.cpp — host-side symbolic setup of the smoothed-aggregation hierarchy (see amg.h).
 #include "amg.h"
+#include "parallel.h"
 
 #include <sched.h>
 
@@ -37,28 +38,6 @@ struct Stopwatch {
 
 struct Triple { int c, x, y; };
 inline bool triple_less(const Triple& p, const Triple& q) { return p.c != q.c ? p.c < q.c : (p.x != q.x ? p.x < q.x : p.y < q.y); }
-
-int host_threads() {
-    if (const char* e = getenv("TSGO_HOST_THREADS")) return std::max(1, atoi(e));
-    cpu_set_t set; CPU_ZERO(&set);
-    int n = 0;
-    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
-    if (n <= 0) n = (int)std::thread::hardware_concurrency();
-    return std::max(1, std::min(16, n / 2));     // half the logical CPUs, at most 16 (one GPU's share of an 8-GPU host)
-}
-
-// f(chunk, begin, end) over [0, n) split into contiguous chunks, one std::thread each.
-template <typename F> int parallel_chunks(int n, F f) {
-    const int nt = std::max(1, std::min(host_threads(), n / 8));
-    if (nt == 1) { f(0, 0, n); return 1; }
-    std::vector<std::thread> th;
-    for (int c = 0; c < nt; ++c) {
-        const int b = (int)((int64_t)n * c / nt), e = (int)((int64_t)n * (c + 1) / nt);
-        th.emplace_back([=, &f] { f(c, b, e); });
-    }
-    for (auto& t : th) t.join();
-    return nt;
-}
 
 template <typename V> void append(std::vector<V>& dst, const std::vector<V>& src) { dst.insert(dst.end(), src.begin(), src.end()); }
 
@@ -222,6 +201,7 @@ std::string coarsen(AmgLevel& L, const std::vector<double>& xy, std::vector<char
         L.rel[2 * (size_t)i] = rigid[i] ? xy[2 * (size_t)i] - xy_next[2 * (size_t)L.agg[i]] : 0.0;
         L.rel[2 * (size_t)i + 1] = rigid[i] ? xy[2 * (size_t)i + 1] - xy_next[2 * (size_t)L.agg[i] + 1] : 0.0;
     }
+    L.rig.assign(rigid.begin(), rigid.end());
     {
         std::vector<char> next(na, 0);
         for (int i = 0; i < n; ++i) next[L.agg[i]] |= rigid[i];
@@ -565,6 +545,25 @@ std::string build_amg_sharded(const tsgo_graph& g, const Problem& local, AmgSym&
     S.schur = std::move(mine);
     out = std::move(S);
     return std::string();
+}
+
+void refresh_amg_geometry(const std::vector<double>& pose_xyt, AmgSym& amg) {
+    if (amg.levels.empty()) return;
+    const int P = amg.levels[0].n;
+    std::vector<double> xy((size_t)P * 2), next;
+    for (int i = 0; i < P; ++i) { xy[2 * (size_t)i] = pose_xyt[3 * (size_t)i]; xy[2 * (size_t)i + 1] = pose_xyt[3 * (size_t)i + 1]; }
+    for (AmgLevel& L : amg.levels) {          // the same arithmetic, in the same order, as coarsen()
+        const int n = L.n, na = L.n_agg;
+        next.assign((size_t)na * 2, 0.0);
+        std::vector<int> cnt(na, 0);
+        for (int i = 0; i < n; ++i) { next[2 * (size_t)L.agg[i]] += xy[2 * (size_t)i]; next[2 * (size_t)L.agg[i] + 1] += xy[2 * (size_t)i + 1]; ++cnt[L.agg[i]]; }
+        for (int a = 0; a < na; ++a) if (cnt[a]) { next[2 * (size_t)a] /= cnt[a]; next[2 * (size_t)a + 1] /= cnt[a]; }
+        for (int i = 0; i < n; ++i) {
+            L.rel[2 * (size_t)i] = L.rig[i] ? xy[2 * (size_t)i] - next[2 * (size_t)L.agg[i]] : 0.0;
+            L.rel[2 * (size_t)i + 1] = L.rig[i] ? xy[2 * (size_t)i + 1] - next[2 * (size_t)L.agg[i] + 1] : 0.0;
+        }
+        xy.swap(next);
+    }
 }
 
 }  // namespace tsgo

@@ -54,6 +54,7 @@ struct AmgLevel {
     std::vector<int> diag;           // per row: index of its diagonal block
     std::vector<int> agg;            // node -> aggregate
     std::vector<double> rel;         // 2 per node: position relative to the aggregate centroid
+    std::vector<uint8_t> rig;        // per node: rotation couples to translation here (a pose with landmark observations below it)
     BlockCsr P;                      // n x n_agg
     std::vector<int> p_self;         // per P block: 1 when col == agg(row)
     PairList p_src;                  // per P block (i,a): x = A block (i,k) with agg(k) == a, y = k
@@ -89,5 +90,10 @@ std::string build_amg(const Problem& pr, AmgSym& out);
 // blocks are then all-reduced (tsgo_hip.hip: launch_amg_setup).  The diagonal blocks come from the all-reduced
 // linearisation partials and are contributed by rank 0 alone.
 std::string build_amg_sharded(const tsgo_graph& g, const Problem& local, AmgSym& out);
+
+// A request with the same structure but new pose estimates reuses every pattern; only the rigid-mode lever arms
+// (AmgLevel::rel: node positions relative to their aggregate's centroid) depend on the estimates.  Recomputes them on
+// every level from pose_xyt (3 per pose, internal numbering), exactly as build_amg does.
+void refresh_amg_geometry(const std::vector<double>& pose_xyt, AmgSym& amg);
 
 }  // namespace tsgo

@@ -28,6 +28,11 @@ bool invert3(const double* m, double* out) {
     return true;
 }
 
+void lm_static(const double* meas, const double* inf, double* out4) {
+    out4[LM_ZX] = meas[0] * std::cos(meas[1]); out4[LM_ZY] = meas[0] * std::sin(meas[1]);   // EdgeSe2Point2d.h:34-35
+    out4[LM_W0] = inf[0]; out4[LM_W1] = inf[1];
+}
+
 namespace {
 
 // Lanes per vertex, from the sweep in profiles/r01c (100k poses, MI355X): the landmark passes want ~1-2
@@ -61,7 +66,7 @@ std::vector<int> window_sort(const std::vector<int>& degree) {
 
 // Shapes a SELL table for per-vertex degrees (internal numbering) and returns, through `place`,
 // a function-like table: slot_of(v, k) = position of the k-th entry of vertex v.
-void shape_table(SellTable& t, int G, const std::vector<int>& degree, int n_planes) {
+void shape_table(SellTable& t, int G, const std::vector<int>& degree, int n_planes, bool with_planes) {
     t.G = G; t.n_vertices = (int)degree.size(); t.n_planes = n_planes;
     const int vps = kWave / G;
     t.n_slices = (t.n_vertices + vps - 1) / vps;
@@ -74,7 +79,7 @@ void shape_table(SellTable& t, int G, const std::vector<int>& degree, int n_plan
     t.rows = t.row_off[t.n_slices];
     t.idx.assign(t.slots(), 0u);
     t.edge.assign(t.slots(), kNoEdge);
-    t.planes.assign((size_t)n_planes * t.slots(), 0.0);
+    if (with_planes) t.planes.assign((size_t)n_planes * t.slots(), 0.0); else t.planes.clear();
 }
 
 inline size_t slot_of(const SellTable& t, int v, int k) {
@@ -212,9 +217,9 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
     if (Gl == 0) Gl = auto_lanes_lm(L ? (double)pr.n_lm_edges / L : 0.0);
     if (!valid_lanes(Gp) || !valid_lanes(Gl)) return "lanes per vertex must be 1, 2, 4 or 8";
 
-    shape_table(pr.by_pose, Gp, dP, LM_PLANES);
-    shape_table(pr.by_lm, Gl, dL, LM_PLANES);
-    shape_table(pr.odom, Gp, dO, OD_PLANES);
+    shape_table(pr.by_pose, Gp, dP, LM_PLANES, opt.fill_planes);
+    shape_table(pr.by_lm, Gl, dL, LM_PLANES, opt.fill_planes);
+    shape_table(pr.odom, Gp, dO, OD_PLANES, opt.fill_planes);
 
     // ---- fill ----------------------------------------------------------------------------------------
     std::vector<int> fillP(P, 0), fillL(L, 0), fillO(P, 0);
@@ -225,12 +230,14 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
             const int c = cls[ev2[e]];
             if (c < pr.lm_first || c >= pr.lm_last) continue;
             const int p = pose_internal[cls[ev1[e]]], l = lm_internal[c - pr.lm_first];
-            const double zx = m[0] * std::cos(m[1]), zy = m[0] * std::sin(m[1]);   // EdgeSe2Point2d.h:34-35
             const size_t sp = slot_of(pr.by_pose, p, fillP[p]++), sl = slot_of(pr.by_lm, l, fillL[l]++);
             pr.by_pose.idx[sp] = (uint32_t)l; pr.by_pose.edge[sp] = (uint32_t)e;
             pr.by_lm.idx[sl] = (uint32_t)p; pr.by_lm.edge[sl] = (uint32_t)e;
-            const double vals[LM_PLANES] = {zx, zy, w[0], w[1]};
-            for (int k = 0; k < LM_PLANES; ++k) { pr.by_pose.plane(k)[sp] = vals[k]; pr.by_lm.plane(k)[sl] = vals[k]; }
+            if (opt.fill_planes) {
+                double vals[LM_PLANES];
+                lm_static(m, w, vals);
+                for (int k = 0; k < LM_PLANES; ++k) { pr.by_pose.plane(k)[sp] = vals[k]; pr.by_lm.plane(k)[sl] = vals[k]; }
+            }
         } else {
             double inv[9];
             if (!invert3(m, inv)) return "ODOM edge " + std::to_string(e) + " has a singular measurement matrix";
@@ -241,8 +248,10 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
                 const size_t so = slot_of(pr.odom, self, fillO[self]++);
                 pr.odom.idx[so] = (uint32_t)other | (side ? kDirBit : 0u);
                 pr.odom.edge[so] = (uint32_t)e;
-                for (int k = 0; k < 6; ++k) pr.odom.plane(OD_MI0 + k)[so] = inv[k];
-                for (int k = 0; k < 3; ++k) pr.odom.plane(OD_W0 + k)[so] = w[k];
+                if (opt.fill_planes) {
+                    for (int k = 0; k < 6; ++k) pr.odom.plane(OD_MI0 + k)[so] = inv[k];
+                    for (int k = 0; k < 3; ++k) pr.odom.plane(OD_W0 + k)[so] = w[k];
+                }
             }
         }
     }

@@ -68,6 +68,8 @@ struct Problem {
 struct BuildOptions {
     int rank = 0, world = 1;
     int lanes_per_pose = 0, lanes_per_lm = 0;   // 0 = auto
+    bool fill_planes = true;    // false: leave SellTable::planes empty (the device engine stages them itself, in its own
+                                // scalar type and plane order, straight into pinned memory: tsgo_hip.hip stage_static_*)
 };
 
 // Returns empty string on success, otherwise the error text.
@@ -75,5 +77,10 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
 
 // general 3x3 inverse in double; false if singular
 bool invert3(const double* m, double* out);
+
+// The four static per-slot values of an LM edge (zx, zy, w0, w1) from its measurement (range, bearing) and information
+// diagonal — ONE definition, shared by build_problem and by the engine's staging/refill path, so that a refilled table
+// holds the same bits as a freshly built one.
+void lm_static(const double* meas, const double* inf, double* out4);
 
 }  // namespace tsgo

@@ -88,11 +88,19 @@ struct Server {
     void connection_end() { { std::lock_guard<std::mutex> lock(conn_mutex); --live_connections; } conn_cv.notify_all(); }
     void drain() { std::unique_lock<std::mutex> lock(conn_mutex); conn_cv.wait(lock, [this] { return live_connections == 0; }); }
 
-    // an engine handle for one request: an idle one, a new one while fewer than max_engines exist, else wait
-    tsgo_optimizer* acquire() {
+    // An engine handle for one request: the one this connection used last when it is idle (it still holds that
+    // connection's graph structure: a repeated structure only refills values, tsgo_config::reuse_structure), else an
+    // idle one, else a new one while fewer than max_engines exist, else wait.
+    tsgo_optimizer* acquire(tsgo_optimizer* preferred = nullptr) {
         std::unique_lock<std::mutex> lock(pool_mutex);
         for (;;) {
-            if (!idle.empty()) { tsgo_optimizer* o = idle.back(); idle.pop_back(); return o; }
+            if (preferred) {
+                auto it = std::find(idle.begin(), idle.end(), preferred);
+                if (it != idle.end()) { idle.erase(it); return preferred; }
+            }
+            // an engine nobody's connection prefers would be ideal; without that bookkeeping take the least recently released one,
+            // which leaves the most recently used handles (and their cached structures) to the connections that used them
+            if (!idle.empty()) { tsgo_optimizer* o = idle.front(); idle.erase(idle.begin()); return o; }
             if (created < max_engines) {
                 tsgo_optimizer* o = nullptr;
                 if (tsgo_create(&cfg, &o)) return nullptr;
@@ -108,20 +116,34 @@ struct Server {
     }
 
     // one request: remote/app/ConnectionHandler.h:14-34
-    bool handle(int fd, std::vector<uint8_t>& payload) {
+    // What a connection keeps from message to message (the reference re-creates everything per message,
+    // ConnectionHandler.h:18-21): the receive buffer, the decoded graph's arrays, the reply buffer — grow-only, so a
+    // client that resends a growing graph does not make the server fault in fresh pages every time — and the engine it
+    // used last.
+    struct Session {
+        std::vector<uint8_t> payload, reply;
+        std::vector<double> v_pos;
+        tsgo_wire_graph* w = tsgo_wire_new();
+        tsgo_optimizer* last_engine = nullptr;
+        ~Session() { tsgo_wire_free(w); }
+    };
+
+    bool handle(int fd, Session& ss) {
         BlockTimer total{"Total"};
-        tsgo_wire_graph* w = nullptr;
+        tsgo_wire_graph* w = ss.w;
         {
             BlockTimer t{"DeserializeGraph"};
-            if (tsgo_wire_decode(payload.data(), payload.size(), &w)) { std::cerr << tsgo_last_error() << std::endl; return false; }
+            if (tsgo_wire_decode_into(w, ss.payload.data(), ss.payload.size())) { std::cerr << tsgo_last_error() << std::endl; return false; }
         }
         tsgo_graph view; tsgo_wire_view(w, &view);
-        std::vector<double> v_pos((size_t)view.n_vertices * 3);
-        std::vector<uint8_t> reply;
+        std::vector<double>& v_pos = ss.v_pos; v_pos.resize((size_t)view.n_vertices * 3);
+        std::vector<uint8_t>& reply = ss.reply;
+        tsgo_optimizer*& last_engine = ss.last_engine;
         bool ok = true;
         {
-            tsgo_optimizer* opt = acquire();
-            if (!opt) { std::cerr << tsgo_last_error() << std::endl; tsgo_wire_free(w); return false; }
+            tsgo_optimizer* opt = acquire(last_engine);
+            if (!opt) { std::cerr << tsgo_last_error() << std::endl; return false; }
+            last_engine = opt;
             struct Give { Server& s; tsgo_optimizer* o; ~Give() { s.release(o); } } give{*this, opt};
             BlockTimer t{"OptimizeHIP"};
             tsgo_stats st;
@@ -133,7 +155,7 @@ struct Server {
                 if (st.stop_reason == TSGO_STOP_CONVERGED) std::cout << "CONVERGED\n";                // :175
                 std::cout << "Summary() error = " << st.chi2_last << std::endl;                        // :182
                 std::cout << " [hip] iterations=" << st.iterations_run << " pcg_iters=" << st.pcg_iters_total
-                          << " setup=" << st.ms_setup << "ms linearize=" << st.ms_linearize << "ms solve=" << st.ms_solve
+                          << (st.structure_reused ? " structure=reused refill=" : " structure=built setup=") << st.ms_setup << "ms linearize=" << st.ms_linearize << "ms solve=" << st.ms_solve
                           << "ms update=" << st.ms_update << "ms" << std::endl;
             }
         }
@@ -143,7 +165,6 @@ struct Server {
             if (n < 0) { std::cerr << tsgo_last_error() << std::endl; ok = false; }
             else { reply.resize((size_t)n); tsgo_wire_encode_response(w, v_pos.data(), reply.data(), reply.size()); }
         }
-        tsgo_wire_free(w);
         if (!ok) return false;
         BlockTimer t{"Sending"};
         std::cout << "SendSync() data size = " << reply.size() << std::endl;     // ConnectionHandlerBase.h:118
@@ -153,14 +174,15 @@ struct Server {
     void connection(int fd) {
         std::cout << "\n------ New Connection ------\n";                         // ConnectionHandler.h:10
         int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-        std::vector<uint8_t> payload;
+        Session ss;
+        std::vector<uint8_t>& payload = ss.payload;
         for (;;) {
             int32_t size = 0;                                                    // ConnectionHandlerGraph.h:37-43,57
             if (!read_exact(fd, &size, sizeof(size))) break;
             if (size <= 0) { std::cerr << "bad graph size " << size << std::endl; break; }
             payload.resize((size_t)size);
             if (!read_exact(fd, payload.data(), payload.size())) break;
-            if (!handle(fd, payload)) break;
+            if (!handle(fd, ss)) break;
         }
         ::close(fd);
     }

@@ -20,6 +20,7 @@
 #include "../../include/tsgo.h"
 #include "host/amg.h"
 #include "host/errors.h"
+#include "host/parallel.h"
 #include "host/problem.h"
 #include "tsgo_amg_kernels.h"
 #include "tsgo_kernels.h"
@@ -125,6 +126,27 @@ template <typename T> struct Engine : IEngine {
     std::vector<void*> allocs;
     bool have_graph_data = false;
     double ms_setup = 0;
+    // Structure of the graph the device tables were built for (a SLAM front-end resends the same
+    // graph with new estimates).  A request with the same vertex ids / types, edge list and fixed list only refills
+    // state and measurement planes: no layout build, no multigrid patterns, no table or hierarchy upload, no capture.
+    struct Structure {
+        std::vector<uint32_t> v_id, v_type, e_type, e_ids, fixed;
+        bool same_as(const tsgo_graph& g) const {
+            auto eq = [](const std::vector<uint32_t>& a, const uint32_t* b, size_t n) { return a.size() == n && (n == 0 || std::memcmp(a.data(), b, n * sizeof(uint32_t)) == 0); };
+            return g.n_vertices >= 0 && g.n_edges >= 0 && g.n_fixed >= 0 && eq(v_id, g.v_id, (size_t)g.n_vertices) && eq(v_type, g.v_type, (size_t)g.n_vertices) &&
+                   eq(e_type, g.e_type, (size_t)g.n_edges) && eq(e_ids, g.e_ids, 2 * (size_t)g.n_edges) && eq(fixed, g.fixed, (size_t)g.n_fixed);
+        }
+        void take(const tsgo_graph& g) {
+            v_id.assign(g.v_id, g.v_id + g.n_vertices); v_type.assign(g.v_type, g.v_type + g.n_vertices);
+            e_type.assign(g.e_type, g.e_type + g.n_edges); e_ids.assign(g.e_ids, g.e_ids + 2 * (size_t)g.n_edges);
+            fixed.assign(g.fixed, g.fixed + g.n_fixed);
+        }
+    } structure;
+    int structure_reuses = 0;
+    bool last_set_reused = false;
+    std::vector<double> lm_values;                 // per LM edge: (zx, zy, w0, w1), scratch of stage_values
+    T* stage = nullptr; size_t stage_cap = 0;      // pinned staging for everything that goes to the device in type T
+    T *st_p = nullptr, *st_l = nullptr, *st_o = nullptr;   // the static planes of the three tables (Table<T>::st, writable)
 
     // device
     T *ps = nullptr, *theta = nullptr, *lmrec = nullptr, *gauge_p = nullptr, *gauge_l = nullptr;
@@ -172,7 +194,7 @@ template <typename T> struct Engine : IEngine {
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
 
-    ~Engine() override { release(); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    ~Engine() override { release(); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 
     void release() {
         if (amg_builder.joinable()) amg_builder.join();
@@ -183,6 +205,14 @@ template <typename T> struct Engine : IEngine {
         if (h_scratch) { (void)hipHostFree(h_scratch); h_scratch = nullptr; }
         if (h_rho) { (void)hipHostFree(h_rho); h_rho = nullptr; }
         have_graph_data = false;
+    }
+    // The staging buffer survives release(): it is sized by the largest table seen and reused across requests.
+    int stage_reserve(size_t n) {
+        if (n <= stage_cap) return 0;
+        if (stage) { (void)hipHostFree(stage); stage = nullptr; stage_cap = 0; }
+        HIP_OK(hipHostMalloc((void**)&stage, n * sizeof(T)));
+        stage_cap = n;
+        return 0;
     }
 
     int init() {
@@ -299,33 +329,19 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&pw_b, (size_t)pr.P * 3)) return rc;
         if (int rc = dalloc(&rho_part, 16 * 2 * kRhoBlocks)) return rc;
         if (lv.size() > 16) return set_error(-2, "tsgo_set_graph: too many multigrid levels");
-        {
-            std::vector<T> init(16, (T)kSmootherOmega); init[0] = (T)kSmoother0Omega;
-            { if (int rc_ = copy_sync(omega_dev, init.data(), 16 * sizeof(T), hipMemcpyHostToDevice)) return rc_; }
-            omega_host.assign(lv.size(), kSmootherOmega); omega_host[0] = kSmoother0Omega;
-        }
         if (h_rho) (void)hipHostFree(h_rho);
         HIP_OK(hipHostMalloc((void**)&h_rho, sizeof(T) * 16 * 2 * kRhoBlocks));
         lin_count = 0; hier_age = -1;
         return 0;
     }
 
-    int upload_table(Table<T>& t, const SellTable& h, int dyn_planes, bool pairs) {
+    // Device buffers of one slot table (indices uploaded, static planes allocated: they are staged separately).
+    int alloc_table(Table<T>& t, T** st_out, const SellTable& h, int st_planes, int dyn_planes, bool pairs) {
         t.slots = h.slots(); t.n_slices = h.n_slices; t.n_vertices = h.n_vertices; t.xcd = cfg.xcd_map ? 1 : 0;
         if (int rc = upload_u32(&t.row_off, h.row_off)) return rc;
         if (int rc = upload_u32(&t.idx, h.idx)) return rc;
-        T* stp = nullptr;
-        std::vector<double> inter;
-        const double* src = h.planes.data();
-        if (pairs) {      // plane-major (zx | zy | w0 | w1) -> pair-plane-major ((zx,zy) | (w0,w1))
-            const size_t S = h.slots();
-            inter.resize(h.planes.size());
-            for (int q = 0; q < h.n_planes / 2; ++q)
-                for (size_t k = 0; k < S; ++k) { inter[((size_t)q * S + k) * 2] = h.plane(2 * q)[k]; inter[((size_t)q * S + k) * 2 + 1] = h.plane(2 * q + 1)[k]; }
-            src = inter.data();
-        }
-        if (int rc = upload_T(&stp, src, h.planes.size())) return rc;
-        t.st = stp;
+        if (int rc = dalloc(st_out, (size_t)st_planes * h.slots())) return rc;
+        t.st = *st_out;
         if (int rc = dalloc(&t.dyn, (size_t)dyn_planes * h.slots())) return rc;
         t.dyn32 = nullptr;
         if (pairs) { if (int rc = dalloc(&t.dyn32, h.slots())) return rc; { if (int rc_ = fill_zero(t.dyn32, std::max<size_t>(h.slots(), 1) * sizeof(float4))) return rc_; } }
@@ -333,11 +349,115 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
 
+    // ---- what changes from request to request when the structure does not: vertex estimates, measurements, weights.
+    // Everything is written ONCE, in the device's scalar type and plane order, into pinned memory and copied from there
+    // (no vector<double> -> vector<T> -> pageable copy).  Used by the first request of a structure and by every refill,
+    // so a refilled engine holds bit for bit what a fresh one would.
+    //   LM tables  : pair-plane-major [(zx, zy) | (w0, w1)] per slot, padding 0          (host/problem.h: lm_static)
+    //   ODOM table : nine planes, rows 0-1 of the inverse measurement (6) + weights (3)
+    //   state      : ps (x, y, cos, sin), theta, lmrec (lx, ly, 0 ...)
+    int stage_values(const tsgo_graph& g) {
+        const size_t Sp = pr.by_pose.slots(), Sl = pr.by_lm.slots(), So = pr.odom.slots();
+        const size_t P = (size_t)pr.P, L = (size_t)pr.L;
+        const size_t o_p = 0, o_l = o_p + 4 * Sp, o_o = o_l + 4 * Sl, o_ps = o_o + 9 * So, o_th = o_ps + 4 * P, o_lm = o_th + P, total = o_lm + (size_t)kLmRec * std::max<size_t>(L, 1);
+        if (int rc = stage_reserve(total)) return rc;
+        const size_t nE = (size_t)g.n_edges;
+        // per LM edge: its four static values, once (a cos and a sin each), then scattered into both groupings
+        std::vector<double>& ev = lm_values; if (ev.size() < 4 * nE) ev.resize(4 * nE);      // grow-only across requests
+        parallel_chunks((int)nE, [&](int, int b, int e) {
+            for (int k = b; k < e; ++k) if (g.e_type[k] == 1) lm_static(g.e_meas + 9 * (size_t)k, g.e_inf + 3 * (size_t)k, &ev[4 * (size_t)k]);
+        });
+        auto lm_table = [&](const SellTable& h, T* dst) {
+            const size_t S = h.slots();
+            parallel_chunks((int)S, [&](int, int b, int e) {
+                for (int k = b; k < e; ++k) {
+                    const uint32_t ed = h.edge[k];
+                    const double* v = ed == kNoEdge ? nullptr : &ev[4 * (size_t)ed];
+                    dst[2 * (size_t)k] = v ? (T)v[LM_ZX] : T(0); dst[2 * (size_t)k + 1] = v ? (T)v[LM_ZY] : T(0);
+                    dst[2 * (S + (size_t)k)] = v ? (T)v[LM_W0] : T(0); dst[2 * (S + (size_t)k) + 1] = v ? (T)v[LM_W1] : T(0);
+                }
+            });
+        };
+        lm_table(pr.by_pose, stage + o_p);
+        lm_table(pr.by_lm, stage + o_l);
+        int bad_edge = -1;
+        for (size_t k = 0; k < So; ++k) {
+            const uint32_t ed = pr.odom.edge[k];
+            T* dst = stage + o_o;
+            if (ed == kNoEdge) { for (int m = 0; m < 9; ++m) dst[(size_t)m * So + k] = T(0); continue; }
+            double inv[9];
+            if (!invert3(g.e_meas + 9 * (size_t)ed, inv)) { bad_edge = (int)ed; break; }
+            for (int m = 0; m < 6; ++m) dst[(size_t)(OD_MI0 + m) * So + k] = (T)inv[m];
+            for (int m = 0; m < 3; ++m) dst[(size_t)(OD_W0 + m) * So + k] = (T)g.e_inf[3 * (size_t)ed + m];
+        }
+        if (bad_edge >= 0) return set_error(-2, "tsgo_set_graph: ODOM edge " + std::to_string(bad_edge) + " has a singular measurement matrix");
+        for (size_t i = 0; i < P; ++i) {
+            const double* v = g.v_pos + 3 * (size_t)pr.pose_vertex[i];
+            pr.pose_xyt[3 * i] = v[0]; pr.pose_xyt[3 * i + 1] = v[1]; pr.pose_xyt[3 * i + 2] = v[2];
+            stage[o_ps + 4 * i] = (T)v[0]; stage[o_ps + 4 * i + 1] = (T)v[1]; stage[o_ps + 4 * i + 2] = (T)std::cos(v[2]); stage[o_ps + 4 * i + 3] = (T)std::sin(v[2]);
+            stage[o_th + i] = (T)v[2];
+        }
+        std::fill(stage + o_lm, stage + o_lm + (size_t)kLmRec * std::max<size_t>(L, 1), T(0));
+        for (size_t l = 0; l < L; ++l) {
+            const double* v = g.v_pos + 3 * (size_t)pr.lm_vertex[l];
+            pr.lm_xy[2 * l] = v[0]; pr.lm_xy[2 * l + 1] = v[1];
+            stage[o_lm + l * kLmRec] = (T)v[0]; stage[o_lm + l * kLmRec + 1] = (T)v[1];
+        }
+        auto put = [&](T* dst, size_t off, size_t n) -> int { if (n) HIP_OK(hipMemcpyAsync(dst, stage + off, n * sizeof(T), hipMemcpyHostToDevice, stream)); return 0; };
+        if (int rc = put(st_p, o_p, 4 * Sp)) return rc;
+        if (int rc = put(st_l, o_l, 4 * Sl)) return rc;
+        if (int rc = put(st_o, o_o, 9 * So)) return rc;
+        if (int rc = put(ps, o_ps, 4 * P)) return rc;
+        if (int rc = put(theta, o_th, P)) return rc;
+        if (int rc = put(lmrec, o_lm, (size_t)kLmRec * std::max<size_t>(L, 1))) return rc;
+        return 0;       // the caller synchronises the stream before the staging buffer is touched again
+    }
+
+    // solver state a fresh engine starts from: whatever was learnt on the previous graph must not leak into this one
+    int reset_solver_state() {
+        have_prev = false; predicted_cg = 0; lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
+        const T one = 1;
+        { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
+        { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
+        if (amg_on) {
+            std::vector<T> init(16, (T)kSmootherOmega); init[0] = (T)kSmoother0Omega;
+            { if (int rc_ = copy_sync(omega_dev, init.data(), 16 * sizeof(T), hipMemcpyHostToDevice)) return rc_; }
+            omega_host.assign(lv.size(), kSmootherOmega); if (!omega_host.empty()) omega_host[0] = kSmoother0Omega;
+        }
+        return 0;
+    }
+
+    // Same structure as the graph the tables were built for: refill values, keep everything else.
+    int refill(const tsgo_graph& g) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (int rc = stage_values(g)) { have_graph_data = false; return rc; }
+        if (amg_on) {           // the rigid-mode lever arms follow the new estimates (host/amg.h: refresh_amg_geometry)
+            refresh_amg_geometry(pr.pose_xyt, amg);
+            HIP_OK(hipStreamSynchronize(stream));
+            for (size_t l = 0; l < amg.levels.size(); ++l) {
+                const std::vector<double>& rel = amg.levels[l].rel;
+                if (int rc = stage_reserve(rel.size())) return rc;
+                for (size_t k = 0; k < rel.size(); ++k) stage[k] = (T)rel[k];
+                if (!rel.empty()) { if (int rc_ = copy_sync(lv[l].rel, stage, rel.size() * sizeof(T), hipMemcpyHostToDevice)) return rc_; }
+            }
+        }
+        if (int rc = reset_solver_state()) return rc;
+        HIP_OK(hipStreamSynchronize(stream));
+        ++structure_reuses;
+        ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (cfg.verbose || getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] set_graph: same structure as the previous graph: values refilled in %.1f ms\n", ms_setup);
+        return 0;
+    }
+
     int set_graph(const tsgo_graph& g) override {
         const auto t0 = std::chrono::steady_clock::now();
         HIP_OK(hipSetDevice(cfg.device));
+        if (g.n_vertices < 0 || g.n_edges < 0 || g.n_fixed < 0) return set_error(-2, "tsgo_set_graph: negative count");
+        last_set_reused = have_graph_data && cfg.reuse_structure && structure.same_as(g);
+        if (last_set_reused) return refill(g);
         release();
         BuildOptions bo; bo.rank = cfg.rank; bo.world = cfg.world; bo.lanes_per_pose = cfg.lanes_per_pose; bo.lanes_per_lm = cfg.lanes_per_lm;
+        bo.fill_planes = false;
         const std::string err = build_problem(g, bo, pr);
         if (!err.empty()) return set_error(-2, "tsgo_set_graph: " + err);
         const bool say = cfg.verbose || getenv("TSGO_VERBOSE");
@@ -352,23 +472,15 @@ template <typename T> struct Engine : IEngine {
         amg_on = cfg.preconditioner == 1 && pr.P > kCoarsestMax;
         if (amg_on) start_amg_builder(g);
         struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{amg_builder};   // on every error path too
-        // state
-        std::vector<double> ps_h((size_t)P * 4), th_h(P);
-        for (int i = 0; i < P; ++i) {
-            th_h[i] = pr.pose_xyt[3 * (size_t)i + 2];
-            ps_h[4 * (size_t)i] = pr.pose_xyt[3 * (size_t)i]; ps_h[4 * (size_t)i + 1] = pr.pose_xyt[3 * (size_t)i + 1];
-            ps_h[4 * (size_t)i + 2] = std::cos(th_h[i]); ps_h[4 * (size_t)i + 3] = std::sin(th_h[i]);
-        }
-        if (int rc = upload_T(&ps, ps_h.data(), ps_h.size())) return rc;
-        if (int rc = upload_T(&theta, th_h.data(), th_h.size())) return rc;
-        std::vector<double> lm_h((size_t)std::max(L, 1) * kLmRec, 0.0);
-        for (int l = 0; l < L; ++l) { lm_h[(size_t)l * kLmRec] = pr.lm_xy[2 * (size_t)l]; lm_h[(size_t)l * kLmRec + 1] = pr.lm_xy[2 * (size_t)l + 1]; }
-        if (int rc = upload_T(&lmrec, lm_h.data(), lm_h.size())) return rc;
+        if (int rc = dalloc(&ps, (size_t)P * 4)) return rc;
+        if (int rc = dalloc(&theta, (size_t)P)) return rc;
+        if (int rc = dalloc(&lmrec, (size_t)std::max(L, 1) * kLmRec)) return rc;
         if (int rc = upload_T(&gauge_p, pr.gauge_p.data(), pr.gauge_p.size())) return rc;
         if (int rc = upload_T(&gauge_l, pr.gauge_l.data(), pr.gauge_l.size())) return rc;
-        if (int rc = upload_table(tp, pr.by_pose, 4, true)) return rc;
-        if (int rc = upload_table(tl, pr.by_lm, 4, true)) return rc;
-        if (int rc = upload_table(to, pr.odom, 3, false)) return rc;
+        if (int rc = alloc_table(tp, &st_p, pr.by_pose, 4, 4, true)) return rc;
+        if (int rc = alloc_table(tl, &st_l, pr.by_lm, 4, 4, true)) return rc;
+        if (int rc = alloc_table(to, &st_o, pr.odom, 9, 3, false)) return rc;
+        if (int rc = stage_values(g)) return rc;
         // table-kernel grids are multiples of 8 (one eighth of the slices per XCD, see xcd_block())
         nbP = 8 * (((tp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);
         nbL = 8 * (((tl.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);
@@ -393,13 +505,12 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&one_dev, 1)) return rc;
         if (int rc = dalloc(&gscale_dev, 1)) return rc;
         if (int rc = dalloc(&xprev, (size_t)P * 3)) return rc;
-        have_prev = false;
-        { const T one = 1; { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; } { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; } }
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
         HIP_OK(hipStreamSynchronize(stream));
         lap("state + slot tables to the device");
         if (amg_on) { if (int rc = upload_amg()) return rc; }
+        if (int rc = reset_solver_state()) return rc;
         HIP_OK(hipStreamSynchronize(stream));
         if (say) std::fprintf(stderr, "[tsgo] set_graph:   of which multigrid patterns on the host %8.1f ms\n", ms_amg_symbolic);
         if (say) for (size_t l = 0; l < lv.size(); ++l)
@@ -407,10 +518,10 @@ template <typename T> struct Engine : IEngine {
                          lv[l].pairs_T, lv[l].nnzT, lv[l].pairs_A, lv[l].n_upper);
         lap("multigrid patterns + upload");
         have_graph_data = true;
-        predicted_cg = 0;
         if (cfg.use_graphs && !collective()) { if (int rc = capture_cg_graph()) return rc; }
         lap("hipGraph capture");
         if (say) std::fprintf(stderr, "[tsgo] set_graph: %d hipMalloc calls took %.1f ms in total\n", n_malloc, ms_in_malloc);
+        structure.take(g);
         ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return 0;
     }
@@ -777,7 +888,7 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipSetDevice(cfg.device));
         tsgo_stats s; std::memset(&s, 0, sizeof(s));
         s.n_pose = pr.P; s.n_lm = pr.L_total; s.n_odom_edges = pr.n_odom_edges_total; s.n_lm_edges = pr.n_lm_edges_total;
-        s.ms_setup = ms_setup;
+        s.ms_setup = ms_setup; s.structure_reused = last_set_reused ? 1 : 0;
         double prevErr = -1; int penalty = 0;
         bool nl2_whole = true;        // sharded: last_delta_norm holds every rank's landmark part (see landmark_norm_allreduce)
         double np2_last = 0, nl2_last = 0;

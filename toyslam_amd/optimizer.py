@@ -16,7 +16,8 @@ STOP = {0: "cap", 1: "worse", 2: "plateau", 3: "converged", 4: "solver_failed"}
 
 class HipOptimizer:
     def __init__(self, device=0, precision=64, pcg_rel_tol=1e-10, pcg_max_iters=20000, lanes_per_pose=0,
-                 lanes_per_lm=0, use_graphs=True, rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None):
+                 lanes_per_lm=0, use_graphs=True, rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None,
+                 reuse_structure=None):
         self.lib = _lib.hip_lib()
         cfg = _lib.tsgo_config()
         self.lib.tsgo_default_config(C.byref(cfg))
@@ -28,6 +29,8 @@ class HipOptimizer:
             cfg.xcd_map = int(xcd_map)
         if warm_start is not None:
             cfg.warm_start = int(warm_start)
+        if reuse_structure is not None:
+            cfg.reuse_structure = int(reuse_structure)
         self.cfg = cfg
         self.h = C.c_void_p()
         _lib.check(self.lib, self.lib.tsgo_create(C.byref(cfg), C.byref(self.h)), "tsgo_create")
@@ -55,7 +58,7 @@ class HipOptimizer:
         n = st.trace_len
         return dict(iters=st.iterations_run, stop=STOP[st.stop_reason], chi2=np.array(st.chi2[:n]), chi2_last=st.chi2_last,
                     cg_iters=np.array(st.pcg_iters[:n]), delta_norm=st.last_delta_norm, ms_total=st.ms_total,
-                    ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup,
+                    ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup, structure_reused=bool(st.structure_reused),
                     n_pose=st.n_pose, n_lm=st.n_lm, n_odom_edges=st.n_odom_edges, n_lm_edges=st.n_lm_edges,
                     cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks)
 

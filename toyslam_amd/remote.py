@@ -93,6 +93,37 @@ def bytes_to_arrays(b):
                        np.array(emeas).reshape(-1, 9), np.array(einf).reshape(-1, 3), fixed)
 
 
+def bytes_to_vertices(b, like):
+    """Vertex positions (n, 3) of a REPLY payload (no prefix) for a request that was `like` (GraphArrays), in `like`'s vertex
+    order — what python/slam_main.py:196-211 consumes.  Vectorised: a 100k-pose reply holds 300k vertex records.  The reply
+    may list the vertices in any order (the reference's is unordered_map order): records are matched by id."""
+    buf = np.frombuffer(b, dtype=np.uint8)
+    n = int(np.frombuffer(b, dtype="<u4", count=1, offset=0)[0])
+    if n != len(like.v_id):
+        raise ValueError("reply holds %d vertices, the request had %d" % (n, len(like.v_id)))
+    # record lengths depend on the type field of each record: walk them with the request's types first (same order is the
+    # common case), verify the ids, and fall back to a sequential walk if the server reordered them
+    size = np.where(like.v_type == 0, 20, 16).astype(np.int64)
+    off = 4 + np.concatenate(([0], np.cumsum(size)[:-1]))
+    words = buf[: 4 + int(size.sum())]
+
+    def u32_at(o):
+        return (words[o].astype(np.uint32) | (words[o + 1].astype(np.uint32) << 8) | (words[o + 2].astype(np.uint32) << 16) | (words[o + 3].astype(np.uint32) << 24))
+
+    def f32_at(o):
+        return u32_at(o).view(np.float32).astype(np.float64)
+    ids, types = u32_at(off), u32_at(off + 4)
+    if np.array_equal(ids, like.v_id) and np.array_equal(types, like.v_type):
+        out = np.zeros((n, 3))
+        out[:, 0] = f32_at(off + 8); out[:, 1] = f32_at(off + 12)
+        pose = like.v_type == 0
+        out[pose, 2] = f32_at(off[pose] + 16)
+        return out
+    got = bytes_to_arrays(b)
+    order = {int(i): k for k, i in enumerate(got.v_id)}
+    return got.v_pos[[order[int(i)] for i in like.v_id]]
+
+
 class GraphClient:
     """connect() / optimize(graph) / close() as python/remote/graph_client.py:13-59, blocking sockets."""
 

@@ -39,14 +39,14 @@ struct Stopwatch {
 struct Triple { int c, x, y; };
 inline bool triple_less(const Triple& p, const Triple& q) { return p.c != q.c ? p.c < q.c : (p.x != q.x ? p.x < q.x : p.y < q.y); }
 
-template <typename V> void append(std::vector<V>& dst, const std::vector<V>& src) { dst.insert(dst.end(), src.begin(), src.end()); }
+template <typename D, typename S> void append(D& dst, const S& src) { dst.insert(dst.end(), src.begin(), src.end()); }
 
 // Row-wise grouped output of a symbolic product, built per chunk and concatenated in row order.
 struct RowsOut {
     std::vector<int> row_nnz, col, grp_len, x, y, flag;
 };
 void concat(std::vector<RowsOut>& parts, int used, BlockCsr& Z, PairList& pl, std::vector<int>* flag) {
-    Z.ptr.assign(1, 0); Z.col.clear(); pl.ptr.assign(1, 0); pl.x.clear(); pl.y.clear();
+    Z.ptr.assign(1, 0); Z.col.clear(); pl.ptr.clear(); pl.ptr.push_back(0); pl.x.clear(); pl.y.clear();
     if (flag) flag->clear();
     size_t ncol = 0, npair = 0;
     for (int c = 0; c < used; ++c) { ncol += parts[c].col.size(); npair += parts[c].x.size(); }
@@ -107,7 +107,7 @@ std::string spgemm_sym(const BlockCsr& X, const std::vector<int>* x_alias, const
     if (poff[n] > INT32_MAX) return "multigrid gather lists exceed 2^31 pairs";
     const int nnz = Z.ptr[n];
     Z.col.assign(nnz, 0);
-    pl.ptr.assign((size_t)nnz + 1, 0); pl.x.assign((size_t)poff[n], 0); pl.y.assign((size_t)poff[n], 0);
+    pl.ptr.resize((size_t)nnz + 1); pl.x.resize((size_t)poff[n]); pl.y.resize((size_t)poff[n]);      // uninitialised: the fill pass writes every entry
     pl.ptr[nnz] = (int)poff[n];
     Stopwatch sw3; sw3.t = t_begin; sw3.lap("    spgemm count pass");
     parallel_chunks(n, [&](int, int b, int e) {
@@ -348,10 +348,12 @@ int aggregate_by_matching(WGraph& g, std::vector<int>& key, int target, std::vec
 
 }  // namespace
 
-std::string build_amg(const Problem& pr, AmgSym& out) {
+std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progress) {
     if (pr.world != 1) return "the multigrid preconditioner is single-shard";
     Stopwatch sw;
-    AmgSym S;
+    out = AmgSym();
+    AmgSym& S = out;
+    S.levels.reserve(32);        // never reallocates: a consumer may read finished levels while later ones are built
     const int P = pr.P;
     // ---- trajectory order: follow ODOM edges id1 -> id2 where that is a simple chain ------------------
     {
@@ -443,6 +445,7 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
         }
     }
     sw.lap("S pattern + lists");
+    if (progress && progress->schur_ready) progress->schur_ready();
 
     // ---- hierarchy ----------------------------------------------------------------------------------------
     std::vector<double> xy((size_t)P * 2);
@@ -492,6 +495,8 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
         sw.lap("coarsen level");
         const int na = cur.n_agg;
         S.levels.push_back(std::move(cur));
+        if (S.levels.size() >= 32) return "too many multigrid levels";
+        if (progress && progress->level_ready) progress->level_ready((int)S.levels.size());
         cur = AmgLevel();
         cur.n = na; cur.A = std::move(A_next);
         cur.agg.resize(na);
@@ -503,7 +508,6 @@ std::string build_amg(const Problem& pr, AmgSym& out) {
         }
         xy = std::move(xy_next);
     }
-    out = std::move(S);
     return std::string();
 }
 

@@ -15,7 +15,10 @@
 // numeric product is a gather over precomputed (x, y) block-pair lists: no atomics, fixed order.
 #pragma once
 #include <cstdint>
+#include <functional>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "problem.h"
@@ -44,8 +47,23 @@ struct BlockCsr {
     int nnz() const { return (int)col.size(); }
 };
 
+// std::vector<int> whose resize() leaves new elements uninitialised: the pair lists hold 43 M entries at 100k poses and
+// every one of them is written by the fill pass; zero-filling them first costs more than filling them.
+template <typename V> struct DefaultInit {
+    using value_type = V;
+    DefaultInit() = default;
+    template <typename U> DefaultInit(const DefaultInit<U>&) {}
+    V* allocate(size_t n) { return std::allocator<V>().allocate(n); }
+    void deallocate(V* p, size_t n) { std::allocator<V>().deallocate(p, n); }
+    template <typename U> void construct(U* p) { ::new ((void*)p) U; }
+    template <typename U, typename A0, typename... A> void construct(U* p, A0&& a0, A&&... a) { ::new ((void*)p) U(std::forward<A0>(a0), std::forward<A>(a)...); }
+    template <typename U> bool operator==(const DefaultInit<U>&) const { return true; }
+    template <typename U> bool operator!=(const DefaultInit<U>&) const { return false; }
+};
+using ivec = std::vector<int, DefaultInit<int>>;
+
 struct PairList {                    // output block o sums over pairs [ptr[o], ptr[o+1])
-    std::vector<int> ptr, x, y;
+    ivec ptr, x, y;
 };
 
 struct AmgLevel {
@@ -81,8 +99,16 @@ struct AmgSym {
     std::vector<int> order;          // internal pose -> position along the trajectory (visiting order and numbering of the aggregates)
 };
 
-// Builds the hierarchy for a single-shard problem.  Returns "" or an error text.
-std::string build_amg(const Problem& pr, AmgSym& out);
+// Progress of build_amg, for a caller that wants to consume (upload) finished parts while the rest is being built:
+// schur_ready() once out.schur and out.order are final; level_ready(n) when out.levels[0 .. n-1] are final (the vector
+// never reallocates); both are called on the building thread.
+struct AmgProgress {
+    std::function<void()> schur_ready;
+    std::function<void(int)> level_ready;
+};
+
+// Builds the hierarchy for a single-shard problem INTO `out` (cleared first).  Returns "" or an error text.
+std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progress = nullptr);
 
 // Edge-sharded runs (Problem::world > 1): the hierarchy is REPLICATED — every rank builds the same patterns from the
 // whole graph — but the level-0 matrix is summed from per-rank partial blocks: `out.schur` lists, for every S block,

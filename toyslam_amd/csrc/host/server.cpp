@@ -18,6 +18,7 @@
 //   connections) are in flight on the device at once, each on its own engine handle and HIP stream: at
 //   <= 100k poses a solve is a chain of short kernels and two overlap to 1.4x the throughput of one.
 #include <arpa/inet.h>
+#include <malloc.h>
 #include <netdb.h>
 #include <netinet/in.h>
 #include <netinet/tcp.h>
@@ -192,6 +193,11 @@ struct Server {
 
 int main(int argc, char* argv[]) {
     signal(SIGPIPE, SIG_IGN);
+    // A request builds and drops several hundred MB of host arrays.  Left to its defaults glibc hands blocks of that size
+    // back to the kernel on free and faults fresh pages in for the next request (tens of ms per request); this process
+    // keeps them: no mmap-backed blocks, no trimming of the heap top.
+    mallopt(M_MMAP_MAX, 0);
+    mallopt(M_TRIM_THRESHOLD, 0x7fffffff);
     std::cout << "HIP (gfx950) is supported\n";
     try {
         const std::string host = argc < 2 ? "127.0.0.1" : argv[1];
@@ -216,6 +222,19 @@ int main(int argc, char* argv[]) {
         {   // fail at start-up, like the reference, when the pipeline cannot be created at all
             tsgo_optimizer* first = srv.acquire();
             if (!first) { std::cerr << "ConnectionManager error: " << tsgo_last_error() << std::endl; return 1; }
+            {   // one small solve before the first client: loads every kernel's code object and sizes the runtime's pools,
+                // so that the first request does not pay for it (the code objects are per process, not per engine)
+                BlockTimer t{"WarmUp"};
+                tsgo_synth_config sc; sc.n_poses = 2000; sc.lm_per_pose = 8; sc.lm_obs_target = 5.0; sc.loop_closures = 0; sc.seed = 1;
+                tsgo_synth* sy = nullptr;
+                if (tsgo_synth_create(&sc, &sy) == 0) {
+                    tsgo_graph view; tsgo_synth_view(sy, &view);
+                    tsgo_stats st; std::vector<double> v((size_t)view.n_vertices * 3);
+                    if (tsgo_set_graph(first, &view) || tsgo_optimize(first, 2, &st) || tsgo_get_vertices(first, v.data()))
+                        std::cerr << "warm-up: " << tsgo_last_error() << std::endl;
+                    tsgo_synth_free(sy);
+                }
+            }
             srv.release(first);
         }
 

@@ -10,9 +10,11 @@
 #include <algorithm>
 #include <chrono>
 #include <cmath>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -124,6 +126,11 @@ template <typename T> struct Engine : IEngine {
     Problem pr;
     hipStream_t stream = nullptr;
     std::vector<void*> allocs;
+    // Device memory of one graph comes from ONE arena, bump-allocated: tsgo_set_graph with a new structure frees nothing
+    // and allocates nothing as long as the new graph fits (hipFree is synchronous and a request makes ~220 allocations).
+    // The first graph of a handle sizes it: its allocations are individual (and counted); the arena replaces them, with
+    // headroom for a growing graph, at the next rebuild.
+    char* arena = nullptr; size_t arena_cap = 0, arena_used = 0, bytes_wanted = 0;
     bool have_graph_data = false;
     double ms_setup = 0;
     // Structure of the graph the device tables were built for (a SLAM front-end resends the same
@@ -194,13 +201,21 @@ template <typename T> struct Engine : IEngine {
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
 
-    ~Engine() override { release(); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    ~Engine() override { release(); if (arena) (void)hipFree(arena); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 
     void release() {
         if (amg_builder.joinable()) amg_builder.join();
         if (cg_graph) { (void)hipGraphExecDestroy(cg_graph); cg_graph = nullptr; }
         for (void* a : allocs) (void)hipFree(a);
         allocs.clear();
+        if (bytes_wanted > arena_cap) {           // the graph just released did not fit: a bigger arena for the next one
+            if (arena) (void)hipFree(arena);
+            arena = nullptr; arena_cap = 0;
+            const size_t want = bytes_wanted + bytes_wanted / 4 + (size_t(1) << 20);
+            void* ptr = nullptr;
+            if (hipMalloc(&ptr, want) == hipSuccess) { arena = (char*)ptr; arena_cap = want; }
+        }
+        arena_used = 0; bytes_wanted = 0;
         if (h_state) { (void)hipHostFree(h_state); h_state = nullptr; }
         if (h_scratch) { (void)hipHostFree(h_scratch); h_scratch = nullptr; }
         if (h_rho) { (void)hipHostFree(h_rho); h_rho = nullptr; }
@@ -234,8 +249,11 @@ template <typename T> struct Engine : IEngine {
     int fill_zero(void* dst, size_t bytes) { HIP_OK(hipMemsetAsync(dst, 0, bytes, stream)); return 0; }
     template <typename U> int dalloc(U** out, size_t n) {
         void* ptr = nullptr;
+        const size_t bytes = (std::max<size_t>(n, 1) * sizeof(U) + 255) & ~size_t(255);
+        bytes_wanted += bytes;
+        if (arena && arena_used + bytes <= arena_cap) { *out = (U*)(arena + arena_used); arena_used += bytes; return 0; }
         const auto t0 = std::chrono::steady_clock::now();
-        HIP_OK(hipMalloc(&ptr, std::max<size_t>(n, 1) * sizeof(U)));
+        HIP_OK(hipMalloc(&ptr, bytes));
         ms_in_malloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++n_malloc;
         allocs.push_back(ptr);
         *out = (U*)ptr;
@@ -256,11 +274,6 @@ template <typename T> struct Engine : IEngine {
         *out = d;
         return 0;
     }
-    int upload_i32(int** out, const std::vector<int>& v) {
-        if (int rc = dalloc(out, v.size())) return rc;
-        if (!v.empty()) { if (int rc_ = copy_sync(*out, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice)) return rc_; }
-        return 0;
-    }
     int upload_u32m(uint32_t** out, const std::vector<uint32_t>& v) {
         if (int rc = dalloc(out, v.size())) return rc;
         if (!v.empty()) { if (int rc_ = copy_sync(*out, v.data(), v.size() * sizeof(uint32_t), hipMemcpyHostToDevice)) return rc_; }
@@ -271,52 +284,89 @@ template <typename T> struct Engine : IEngine {
         for (int i = 0; i < m.n_rows; ++i) for (int a = m.ptr[i]; a < m.ptr[i + 1]; ++a) r[a] = i;
         return r;
     }
-    // The hierarchy's patterns are built by a host thread (host/amg.cpp) while this thread uploads state and slot tables.
+    // The hierarchy's patterns are built by a host thread (host/amg.cpp) while this thread uploads state and slot tables —
+    // and then the finished parts of the hierarchy itself: the contribution lists of level 0 as soon as they exist, every
+    // level as soon as it is complete (a level's gather lists are tens of MB of pageable memory: their copies hide behind
+    // the symbolic work on the next level).  Sharded runs remap the lists after the build and upload everything at the end.
     std::thread amg_builder;
     std::string amg_builder_error;
+    std::mutex amg_mu; std::condition_variable amg_cv;
+    bool amg_schur_ready = false, amg_finished = false; int amg_levels_ready = 0;
     void start_amg_builder(const tsgo_graph& g) {
+        amg_schur_ready = amg_finished = false; amg_levels_ready = 0;
         amg_builder = std::thread([this, &g] {      // g is borrowed for the whole tsgo_set_graph call, which joins this thread
             const auto t0 = std::chrono::steady_clock::now();
-            amg_builder_error = pr.world > 1 ? build_amg_sharded(g, pr, amg) : build_amg(pr, amg);
+            AmgProgress pg;
+            pg.schur_ready = [this] { { std::lock_guard<std::mutex> l(amg_mu); amg_schur_ready = true; } amg_cv.notify_all(); };
+            pg.level_ready = [this](int n) { { std::lock_guard<std::mutex> l(amg_mu); amg_levels_ready = n; } amg_cv.notify_all(); };
+            amg_builder_error = pr.world > 1 ? build_amg_sharded(g, pr, amg) : build_amg(pr, amg, &pg);
             ms_amg_symbolic = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            { std::lock_guard<std::mutex> l(amg_mu); amg_finished = true; }
+            amg_cv.notify_all();
         });
     }
-    int upload_amg() {
-        if (amg_builder.joinable()) amg_builder.join();
-        if (!amg_builder_error.empty()) return set_error(-2, "tsgo_set_graph: " + amg_builder_error);
-        lv.assign(amg.levels.size(), DevLevel<T>());
+    template <typename A> int upload_i32(int** out, const std::vector<int, A>& v) {
+        if (int rc = dalloc(out, v.size())) return rc;
+        if (!v.empty()) { if (int rc_ = copy_sync(*out, v.data(), v.size() * sizeof(int), hipMemcpyHostToDevice)) return rc_; }
+        return 0;
+    }
 #define UP(dst, vec) if (int rc = upload_i32(&dst, vec)) return rc
-        for (size_t l = 0; l < amg.levels.size(); ++l) {
-            const AmgLevel& L = amg.levels[l]; DevLevel<T>& D = lv[l];
-            D.n = L.n; D.n_agg = L.n_agg; D.nnzA = L.A.nnz(); D.nnzP = L.P.nnz(); D.nnzT = L.T.nnz(); D.nnzNext = (int)L.a_src.ptr.size() - 1;
-            D.pairs_T = (double)L.t_src.x.size() / std::max(1, D.nnzT); D.pairs_A = (double)L.a_src.x.size() / std::max<double>(1, (double)std::count(L.a_mirror.begin(), L.a_mirror.end(), -1));
-            UP(D.A_ptr, L.A.ptr); UP(D.A_col, L.A.col); UP(D.A_row, rows_of(L.A)); UP(D.diag, L.diag);
-            UP(D.P_ptr, L.P.ptr); UP(D.P_col, L.P.col); UP(D.P_row, rows_of(L.P)); UP(D.p_self, L.p_self);
-            UP(D.ps_ptr, L.p_src.ptr); UP(D.ps_x, L.p_src.x); UP(D.ps_y, L.p_src.y);
-            UP(D.R_ptr, L.R.ptr); UP(D.R_col, L.R.col); UP(D.r_to_p, L.r_to_p);
-            { std::vector<int> inv(L.r_to_p.size()); for (size_t k = 0; k < inv.size(); ++k) inv[L.r_to_p[k]] = (int)k; UP(D.p_to_r, inv); }
-            UP(D.ts_ptr, L.t_src.ptr); UP(D.ts_x, L.t_src.x); UP(D.ts_y, L.t_src.y);
-            UP(D.as_ptr, L.a_src.ptr); UP(D.as_x, L.a_src.x); UP(D.as_y, L.a_src.y); UP(D.as_mirror, L.a_mirror);
-            { std::vector<int> up; for (int b = 0; b < (int)L.a_mirror.size(); ++b) if (L.a_mirror[b] < 0) up.push_back(b); D.n_upper = (int)up.size(); UP(D.as_upper, up); }
-            if (int rc = upload_T(&D.rel, L.rel.data(), L.rel.size())) return rc;
-            if (int rc = dalloc(&D.A, (size_t)D.nnzA * 9)) return rc;
-            if (int rc = dalloc(&D.Dinv, (size_t)D.n * 9)) return rc;
-            if (int rc = dalloc(&D.P, (size_t)D.nnzP * 9)) return rc;
-            if (int rc = dalloc(&D.Rv, (size_t)D.nnzP * 9)) return rc;
-            if (int rc = dalloc(&D.Tv, (size_t)D.nnzT * 9)) return rc;
-            if (l > 0) {
-                if (int rc = dalloc(&D.r, (size_t)D.n * 3)) return rc;
-                if (int rc = dalloc(&D.z, (size_t)D.n * 3)) return rc;
-                if (int rc = dalloc(&D.res, (size_t)D.n * 3)) return rc;
-                if (int rc = dalloc(&D.z2, (size_t)D.n * 3)) return rc;
-            }
-        }
+    int upload_schur_lists() {
         UP(sc_ptr, amg.schur.ptr); UP(sc_optr, amg.schur.od_ptr);
         if (int rc = upload_u32m(&sc_si, amg.schur.slot_i)) return rc;
         if (int rc = upload_u32m(&sc_sk, amg.schur.slot_k)) return rc;
         if (int rc = upload_u32m(&sc_os, amg.schur.od_slot)) return rc;
+        return 0;
+    }
+    int upload_level(size_t l) {
+        const AmgLevel& L = amg.levels[l]; DevLevel<T>& D = lv[l];
+        D.n = L.n; D.n_agg = L.n_agg; D.nnzA = L.A.nnz(); D.nnzP = L.P.nnz(); D.nnzT = L.T.nnz(); D.nnzNext = (int)L.a_src.ptr.size() - 1;
+        D.pairs_T = (double)L.t_src.x.size() / std::max(1, D.nnzT); D.pairs_A = (double)L.a_src.x.size() / std::max<double>(1, (double)std::count(L.a_mirror.begin(), L.a_mirror.end(), -1));
+        UP(D.A_ptr, L.A.ptr); UP(D.A_col, L.A.col); UP(D.A_row, rows_of(L.A)); UP(D.diag, L.diag);
+        UP(D.P_ptr, L.P.ptr); UP(D.P_col, L.P.col); UP(D.P_row, rows_of(L.P)); UP(D.p_self, L.p_self);
+        UP(D.ps_ptr, L.p_src.ptr); UP(D.ps_x, L.p_src.x); UP(D.ps_y, L.p_src.y);
+        UP(D.R_ptr, L.R.ptr); UP(D.R_col, L.R.col); UP(D.r_to_p, L.r_to_p);
+        { std::vector<int> inv(L.r_to_p.size()); for (size_t k = 0; k < inv.size(); ++k) inv[L.r_to_p[k]] = (int)k; UP(D.p_to_r, inv); }
+        UP(D.ts_ptr, L.t_src.ptr); UP(D.ts_x, L.t_src.x); UP(D.ts_y, L.t_src.y);
+        UP(D.as_ptr, L.a_src.ptr); UP(D.as_x, L.a_src.x); UP(D.as_y, L.a_src.y); UP(D.as_mirror, L.a_mirror);
+        { std::vector<int> up; for (int b = 0; b < (int)L.a_mirror.size(); ++b) if (L.a_mirror[b] < 0) up.push_back(b); D.n_upper = (int)up.size(); UP(D.as_upper, up); }
+        if (int rc = upload_T(&D.rel, L.rel.data(), L.rel.size())) return rc;
+        if (int rc = dalloc(&D.A, (size_t)D.nnzA * 9)) return rc;
+        if (int rc = dalloc(&D.Dinv, (size_t)D.n * 9)) return rc;
+        if (int rc = dalloc(&D.P, (size_t)D.nnzP * 9)) return rc;
+        if (int rc = dalloc(&D.Rv, (size_t)D.nnzP * 9)) return rc;
+        if (int rc = dalloc(&D.Tv, (size_t)D.nnzT * 9)) return rc;
+        if (l > 0) {
+            if (int rc = dalloc(&D.r, (size_t)D.n * 3)) return rc;
+            if (int rc = dalloc(&D.z, (size_t)D.n * 3)) return rc;
+            if (int rc = dalloc(&D.res, (size_t)D.n * 3)) return rc;
+            if (int rc = dalloc(&D.z2, (size_t)D.n * 3)) return rc;
+        }
+        return 0;
+    }
+    int upload_amg() {
+        lv.assign(32, DevLevel<T>());            // host/amg.cpp never builds more levels than this; trimmed below
+        size_t done = 0; bool schur_done = false;
+        if (pr.world == 1) {                     // consume what the builder has finished while it works on the rest
+            for (;;) {
+                int ready; bool schur, fin;
+                {
+                    std::unique_lock<std::mutex> l(amg_mu);
+                    amg_cv.wait(l, [&] { return amg_finished || (int)done < amg_levels_ready || (!schur_done && amg_schur_ready); });
+                    ready = amg_levels_ready; schur = amg_schur_ready; fin = amg_finished;
+                }
+                if (fin) break;                  // whatever is left is uploaded after the join (and errors are looked at there)
+                if (schur && !schur_done) { if (int rc = upload_schur_lists()) return rc; schur_done = true; }
+                for (; (int)done < ready; ++done) if (int rc = upload_level(done)) return rc;
+            }
+        }
+        if (amg_builder.joinable()) amg_builder.join();
+        if (!amg_builder_error.empty()) return set_error(-2, "tsgo_set_graph: " + amg_builder_error);
+        if (amg.levels.size() > 16) return set_error(-2, "tsgo_set_graph: too many multigrid levels");
+        if (!schur_done) { if (int rc = upload_schur_lists()) return rc; }
+        for (; done < amg.levels.size(); ++done) if (int rc = upload_level(done)) return rc;
+        lv.resize(amg.levels.size());
         UP(last_ptr, amg.A_last.ptr); UP(last_col, amg.A_last.col);
-#undef UP
         nb_last = amg.A_last.n_rows; nnz_last = amg.A_last.nnz();
         if (nb_last * 3 > kDenseMax) return set_error(-2, "tsgo_set_graph: coarsest multigrid level too large");
         if (int rc = dalloc(&A_last, (size_t)nnz_last * 9)) return rc;
@@ -328,12 +378,12 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&pw_a, (size_t)pr.P * 3)) return rc;
         if (int rc = dalloc(&pw_b, (size_t)pr.P * 3)) return rc;
         if (int rc = dalloc(&rho_part, 16 * 2 * kRhoBlocks)) return rc;
-        if (lv.size() > 16) return set_error(-2, "tsgo_set_graph: too many multigrid levels");
         if (h_rho) (void)hipHostFree(h_rho);
         HIP_OK(hipHostMalloc((void**)&h_rho, sizeof(T) * 16 * 2 * kRhoBlocks));
         lin_count = 0; hier_age = -1;
         return 0;
     }
+#undef UP
 
     // Device buffers of one slot table (indices uploaded, static planes allocated: they are staged separately).
     int alloc_table(Table<T>& t, T** st_out, const SellTable& h, int st_planes, int dyn_planes, bool pairs) {

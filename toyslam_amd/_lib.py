@@ -99,7 +99,8 @@ def host_lib():
     """libtsgo_host.so: codec, synthetic graphs, layout probe.  No GPU needed."""
     global _host
     if _host is None:
-        path = build.HOST_SO if os.path.exists(build.HOST_SO) else build.build_host()
+        # TSGO_HOST_SO: an instrumented build of the same sources (tools/sanitize_host.sh: ASan + UBSan, CPU only)
+        path = os.environ.get("TSGO_HOST_SO") or (build.HOST_SO if os.path.exists(build.HOST_SO) else build.build_host())
         _host = C.CDLL(path)
         _declare_host(_host)
     return _host

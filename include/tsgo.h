@@ -62,8 +62,9 @@ typedef struct tsgo_config {
     int32_t preconditioner;  /* 1 (default, single shard): smoothed-aggregation multigrid V-cycle on the reduced
                                 pose system; 0: block-Jacobi on its 3x3 diagonal (always used when world > 1) */
     int32_t xcd_map;         /* 1: workgroup -> slice map gives each XCD a contiguous eighth of the vertices; 0: round-robin */
-    int32_t warm_start;      /* 1 (default): PCG starts from (1 - step) * the previous Gauss-Newton iteration's pose delta
-                                (the un-taken remainder of the last step); 0: from zero.  Same answer to pcg_rel_tol. */
+    int32_t warm_start;      /* 0: PCG starts from zero.  1: from (1 - step) * the previous Gauss-Newton iteration's pose delta (the
+                                un-taken remainder of the last step).  2 (default): from the third solve on, extrapolated with the
+                                delta before that as well, (1 - step) * (2 d1 - (1 - step) d2).  Same answer to pcg_rel_tol. */
     int32_t reuse_structure; /* 1 (default): tsgo_set_graph with the SAME vertex ids/types, edge list and fixed list as the graph the
                                 handle already holds only refills estimates, measurements and weights (the reference re-creates
                                 everything per message, remote/app/ConnectionHandler.h:18-21); 0: always rebuild.  Same results. */

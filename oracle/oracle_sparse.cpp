@@ -515,7 +515,7 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
     if (precond == 1 && !tw.enable_amg(g).empty()) return -5;
     std::memcpy(v_pos_out, v_pos, sizeof(double) * 3 * (size_t)nV);
     double prevErr = -1; int penalty = 0;
-    std::vector<double> xprev;
+    std::vector<double> xprev, xprev2;
     *stop_reason = 0; *iters_run = 0; *last_delta_norm = 0;
     if (seconds_lin) *seconds_lin = 0;
     if (seconds_solve) *seconds_solve = 0;
@@ -523,14 +523,20 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
     for (int it = 0; it < iterations; ++it) {
         double t0 = now();
         static const bool cold = getenv("TSGO_TWIN_COLD") != nullptr;
-        const double gamma0 = tw.linearize(it > 0 && !cold ? &xprev : nullptr);
+        static const double ext = getenv("TSGO_TWIN_EXTRAP") ? atof(getenv("TSGO_TWIN_EXTRAP")) : 1.0;     // as Engine::launch_warm (tsgo_hip.hip)
+        std::vector<double> xw;
+        if (it > 1 && ext != 0.0 && xprev2.size() == xprev.size()) {     // x0 = 0.8 (d1 + ext * (d1 - 0.8 d2)) after the 0.8 scaling inside linearize()
+            xw.resize(xprev.size());
+            for (size_t k = 0; k < xw.size(); ++k) xw[k] = xprev[k] + ext * (xprev[k] - (1.0 - tsgo::kStepScale) * xprev2[k]);
+        }
+        const double gamma0 = tw.linearize(it > 0 && !cold ? (xw.empty() ? &xprev : &xw) : nullptr);
         double t1 = now(); if (seconds_lin) *seconds_lin += t1 - t0;
         const double err = tw.chi2;
         chi2_trace[it] = err; *iters_run = it + 1;
         if (prevErr > 0 && err > prevErr) { if (++penalty > 2) { *stop_reason = 1; break; } } else penalty = 0;
         bool ok; cg_trace[it] = tw.solve_with_fallback(gamma0, pcg_tol, max_cg, &ok);
         if (!ok) { *stop_reason = 4; break; }
-        xprev = tw.x;
+        xprev2 = xprev; xprev = tw.x;
         std::vector<double> dl; tw.backsub(dl);
         const double nrm = tw.update(dl);
         if (seconds_solve) *seconds_solve += now() - t1;

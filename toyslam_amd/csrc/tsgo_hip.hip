@@ -177,12 +177,13 @@ template <typename T> struct Engine : IEngine {
     H* A_last = nullptr;
     T *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr;
     double ms_amg_symbolic = 0;
-    T *omega_dev = nullptr, *one_dev = nullptr, *gscale_dev = nullptr, *xprev = nullptr, *pw_a = nullptr, *pw_b = nullptr, *rho_part = nullptr;
+    T *omega_dev = nullptr, *one_dev = nullptr, *gscale_dev = nullptr, *xprev = nullptr, *xprev2 = nullptr, *pw_a = nullptr, *pw_b = nullptr, *rho_part = nullptr;
     T* h_rho = nullptr;                 // pinned
     std::vector<double> omega_host;    // smoother damping per level (diagnostics)
     int lin_count = 0;
     int hier_age = -1, hier_max_age = kHierMaxAge, hier_slack = kHierSlack, iters_fresh = 0, iters_last = 0;   // -1: no valid hierarchy
     bool have_prev = false;            // xprev holds the pose delta of the previous solve (warm start)
+    int n_prev = 0;                    // how many consecutive deltas are held (xprev, xprev2)
     int coarse_sweeps = kCoarseSweeps;
     std::vector<int> sweeps_list;      // research: sweeps per side on levels 1, 2, ... (TSGO_SWEEPS_LIST="2,2,1"; the last entry repeats)
     bool sweeps_forced = false;        // TSGO_COARSE_SWEEPS given: the same count on every coarse level
@@ -465,7 +466,7 @@ template <typename T> struct Engine : IEngine {
 
     // solver state a fresh engine starts from: whatever was learnt on the previous graph must not leak into this one
     int reset_solver_state() {
-        have_prev = false; predicted_cg = 0; lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
+        have_prev = false; n_prev = 0; predicted_cg = 0; lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
         const T one = 1;
         { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
         { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
@@ -555,6 +556,7 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&one_dev, 1)) return rc;
         if (int rc = dalloc(&gscale_dev, 1)) return rc;
         if (int rc = dalloc(&xprev, (size_t)P * 3)) return rc;
+        if (int rc = dalloc(&xprev2, (size_t)P * 3)) return rc;
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
         HIP_OK(hipStreamSynchronize(stream));
@@ -721,10 +723,16 @@ template <typename T> struct Engine : IEngine {
         // iterate of level l after the down pass: L.z when nu is odd, L.z2 when even
         auto down_iter = [&](DevLevel<T>& L, int nu) { return (nu % 2) ? L.z : L.z2; };
         auto down_other = [&](DevLevel<T>& L, int nu) { return (nu % 2) ? L.z2 : L.z; };
-        if (nl > 1) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
+        if (nl > 1 && lv[nl - 1].n * 4 <= kDenseThreads) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
             DevLevel<T>& L = lv[nl - 1];
             hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kDenseThreads), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv, L.P_ptr, L.P_col, (const H*)L.P,
                                (const T*)L.res, (const T*)inv_last, down_iter(L, nu_at(nl - 1)), s);
+        } else if (nl > 1) {   // a last explicit level too long for the one-workgroup kernel (4 lanes per row): the same three steps as launches
+            DevLevel<T>& L = lv[nl - 1];
+            hipLaunchKernelGGL((k_restrict<T, 8, 0>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv,
+                               (const T*)L.res, (const T*)L.res, r_last, (const H*)nullptr, (T*)nullptr, (const T*)one_dev, s);
+            hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
+            launch_prolong(L, z_last, down_iter(L, nu_at(nl - 1)), 3, s);
         } else {        // only level 0 above the dense level: residual r - S z is restricted from (r, sbuf)
             DevLevel<T>& L = lv[0];
             hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv,
@@ -831,7 +839,14 @@ template <typename T> struct Engine : IEngine {
     // is still to go at the next linearisation.  x0 = that remainder, r = b~ - S x0 (one extra product), and the stopping
     // rule keeps measuring against the right-hand side: gamma0 is scaled by (b^T D^-1 b) / (r0^T D^-1 r0).
     int launch_warm() {
-        hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, (T)(1.0 - kStepScale));
+        // x0 = the un-taken remainder of the previous step, (1 - step) d1 — plus, from the third solve on, the same remainder of
+        // what the last step itself added over ITS prediction: with c1 = d1 - (1 - step) d2 the damped iteration repeats
+        // d_next ~ (1 - step) (d1 + c1).  Saves another 1-2 iterations per solve (profiles/r02f_warm_start_extrapolation.txt).
+        const T a = (T)(1.0 - kStepScale);
+        if (n_prev >= 2 && cfg.warm_start >= 2)
+            hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, (T)(2 * a), (const T*)xprev2, (T)(-a * a));
+        else
+            hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, a, (const T*)nullptr, T(0));
         if (int rc = launch_matvec(0)) return rc;
         hipLaunchKernelGGL((k_warm_residual<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)minv, r, zc, (const T*)(amg_on ? omega_dev : one_dev), npart);
         hipLaunchKernelGGL((k_warm_scale<T>), dim3(1), dim3(kBlock), 0, stream, nbC, (const T*)gpart[0], (const T*)npart, amg_on ? (T*)nullptr : gpart[0], gscale_dev);
@@ -844,10 +859,7 @@ template <typename T> struct Engine : IEngine {
             // certify the multigrid-preconditioned solve in a norm the multigrid operator has no part in:
             // r^T D^-1 r against b^T D^-1 b (partials left by k_pose_finalize in gpart[0]).  An indefinite
             // preconditioner can make r^T M^-1 r small while r is not.
-            hipLaunchKernelGGL((k_resid_norm<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, npart);
-            HIP_OK(hipMemcpyAsync(h_scratch, npart, sizeof(T) * nbC, hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipMemcpyAsync(h_scratch + nbC, gpart[0], sizeof(T) * nbC, hipMemcpyDeviceToHost, stream));
-            HIP_OK(hipStreamSynchronize(stream));
+            // (k_resid_norm ran and its partials came back with the device state: do_solve_once)
             double num = 0, den = 0;
             for (int k = 0; k < nbC; ++k) { num += (double)h_scratch[k]; den += (double)h_scratch[nbC + k]; }
             const double lim = kCertifySlack * cfg.pcg_rel_tol;
@@ -890,6 +902,12 @@ template <typename T> struct Engine : IEngine {
             }
             if (timing) std::fprintf(stderr, "[tsgo] solve: %d chunk(s) enqueued at %.0f us", burst, since());
             burst = 1;
+            // the residual certificate (do_solve) rides on the same round trip: its 7 us are wasted only when the look is too early
+            if (amg_on) {
+                hipLaunchKernelGGL((k_resid_norm<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, npart);
+                HIP_OK(hipMemcpyAsync(h_scratch, npart, sizeof(T) * nbC, hipMemcpyDeviceToHost, stream));
+                HIP_OK(hipMemcpyAsync(h_scratch + nbC, gpart[0], sizeof(T) * nbC, hipMemcpyDeviceToHost, stream));
+            }
             HIP_OK(hipMemcpyAsync(h_state, st[0], sizeof(CgState<T>), hipMemcpyDeviceToHost, stream));
             HIP_OK(hipStreamSynchronize(stream));
             if (timing) std::fprintf(stderr, ", drained at %.0f us (iters %d done %d)\n", since(), h_state->iters, h_state->done);
@@ -905,8 +923,9 @@ template <typename T> struct Engine : IEngine {
     // rank: pose vectors are replicated) and THIS rank's ||delta_l||^2 (landmark deltas are shard-local).
     int do_backsub_update(T step, double* np2_out, double* nl2_local_out) {
         const int P = pr.P;
-        hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, zc, xprev, (const T*)nullptr, T(0));
-        have_prev = step != T(0);     // a probe (step 0) leaves nothing to carry over
+        if (step != T(0)) std::swap(xprev, xprev2);      // the delta before this one (a probe, step 0, leaves the history alone)
+        hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, zc, step != T(0) ? xprev : (T*)nullptr, (const T*)nullptr, T(0), (const T*)nullptr, T(0));
+        if (step != T(0)) { have_prev = true; n_prev = std::min(n_prev + 1, 2); } else { have_prev = false; n_prev = 0; }   // a probe leaves nothing to carry over
         if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 1, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[0], step, dl, npart + nbC);
         hipLaunchKernelGGL((k_pose_update<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, ps, theta, step, npart);
         const int nl = tl.n_slices > 0 ? nbL : 0;

@@ -502,16 +502,21 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int P, const T* __restrict
 }
 
 // x -> zc[.][0..2] (the landmark pass reads its vector from zc)
-// scale = 0: plain copy of x into zc (and into xsave when given).  scale != 0: x = scale * xprev first (warm start).
+// scale = 0: plain copy of x into zc (and into xsave when given).  scale != 0 (warm start): x = scale * xprev + scale2 * xprev2
+// first (xprev2 may be null: first term only).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_pack_x(int P, T* __restrict__ x, T* __restrict__ zc, T* __restrict__ xsave,
-                                                   const T* __restrict__ xprev, T scale) {
+                                                   const T* __restrict__ xprev, T scale, const T* __restrict__ xprev2, T scale2) {
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= P) return;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         T v = x[(size_t)i * 3 + k];
-        if (scale != T(0)) { v = scale * xprev[(size_t)i * 3 + k]; x[(size_t)i * 3 + k] = v; }
+        if (scale != T(0)) {
+            v = scale * xprev[(size_t)i * 3 + k];
+            if (xprev2) v += scale2 * xprev2[(size_t)i * 3 + k];
+            x[(size_t)i * 3 + k] = v;
+        }
         zc[(size_t)i * kPoseRec + k] = v;
         if (xsave) xsave[(size_t)i * 3 + k] = v;
     }

@@ -271,6 +271,26 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_inverse(int nb, const i
     for (int e = threadIdx.x; e < n * n; e += kDenseThreads) inv[e] = M[e];
 }
 
+// ---- cycle format --------------------------------------------------------------------------------------------
+// The setup kernels address 3x3 blocks by block index (36 contiguous bytes, "AoS").  Read that way by the cycle kernels —
+// a lane per block, nine loads — every load instruction of a wavefront touches 36-byte-strided words: 18+ cache lines
+// for 256 useful bytes, and the texture addressers, not the memory system, set the pace (profiles/r01e: L1 tag pipes at
+// 40 %).  The cycle therefore reads a COPY in which the blocks of one row are stored plane-major: element m of the j-th
+// block of row i lives at 9 * ptr[i] + m * len_i + j, so that lanes j, j+1, ... load consecutive words.  Same bytes, one
+// or two lines per load instruction.  The copy is written once per hierarchy build (k_to_planes, 8 lanes per row).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_to_planes(int n_rows, const int* __restrict__ ptr, const HT<T>* __restrict__ src, HT<T>* __restrict__ dst) {
+    const int g = (blockIdx.x * kBlock + threadIdx.x) / 8, sub = threadIdx.x % 8;
+    if (g >= n_rows) return;
+    const int p0 = ptr[g], len = ptr[g + 1] - p0;
+    for (int j = sub; j < len; j += 8) {
+        const HT<T>* b = src + (size_t)(p0 + j) * 9;
+        HT<T>* o = dst + (size_t)p0 * 9 + j;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) o[(size_t)m * len] = b[m];
+    }
+}
+
 // ---- V-cycle ---------------------------------------------------------------------------------------
 // The coarse levels hold little work (12.5k / 1.5k / 196 block rows at 100k poses): what matters is the
 // length of the dependent-load chain, so LPR lanes share one block row (one 3x3 block per lane per
@@ -278,7 +298,8 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_inverse(int nb, const i
 
 // MODE 0: out = r - A z.   MODE 1: out = z + omega Dinv (r - A z)  (smoothing sweep).
 // MODE 2: out = Dinv A z  (power iteration for the smoother's damping).
-template <typename T, int LPR, int MODE>
+// PM: A is the plane-major copy (cycle format above); otherwise block-indexed.
+template <typename T, int LPR, int MODE, int PM = 1>
 __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __restrict__ ptr, const int* __restrict__ col,
                                                           const HT<T>* __restrict__ A, const T* __restrict__ r, const T* __restrict__ z,
                                                           const HT<T>* __restrict__ Dinv, T* __restrict__ out,
@@ -288,27 +309,51 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
     // LPR == 64: the row is wave-uniform, its bounds come through the scalar cache (one dependent round trip shorter)
     const int i = LPR == 64 ? __builtin_amdgcn_readfirstlane(g < n ? g : n - 1) : (g < n ? g : n - 1);
     T s0 = 0, s1 = 0, s2 = 0;
-    for (int a = ptr[i] + sub; a < ptr[i + 1]; a += LPR) {
-        const HT<T>* b = A + (size_t)a * 9; const T* v = z + (size_t)col[a] * 3;
+    const int p0 = ptr[i], p1 = ptr[i + 1];
+    // What the row's epilogue needs (its right-hand side, its own entry of z, its diagonal inverse) depends on the row
+    // alone: requested now, it arrives while the blocks are walked instead of adding a fourth dependent trip at the end.
+    const bool head = g < n && sub == 0;
+    T ri0 = 0, ri1 = 0, ri2 = 0, zi0 = 0, zi1 = 0, zi2 = 0;
+    HT<T> d[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    if (head) {
+        if (MODE != 2) { ri0 = r[(size_t)i * 3]; ri1 = r[(size_t)i * 3 + 1]; ri2 = r[(size_t)i * 3 + 2]; }
+        if (MODE == 1) { zi0 = z[(size_t)i * 3]; zi1 = z[(size_t)i * 3 + 1]; zi2 = z[(size_t)i * 3 + 2]; }
+        if (MODE != 0) {
+#pragma unroll
+            for (int m = 0; m < 9; ++m) d[m] = Dinv[(size_t)i * 9 + m];
+        }
+    }
+    const size_t len = (size_t)(p1 - p0);
+    const HT<T>* base = A + (size_t)p0 * 9;
+    for (int a = p0 + sub; a < p1; a += LPR) {
+        const T* v = z + (size_t)col[a] * 3;
+        T b[9];
+        if (PM) {
+            const HT<T>* q = base + (a - p0);
+#pragma unroll
+            for (int m = 0; m < 9; ++m) b[m] = q[(size_t)m * len];
+        } else {
+            const HT<T>* q = A + (size_t)a * 9;
+#pragma unroll
+            for (int m = 0; m < 9; ++m) b[m] = q[m];
+        }
         const T v0 = v[0], v1 = v[1], v2 = v[2];
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
     s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
-    if (g < n && sub == 0) {
+    if (head) {
         if (MODE == 2) {
-            const HT<T>* d = Dinv + (size_t)i * 9;
             out[(size_t)i * 3] = d[0] * s0 + d[1] * s1 + d[2] * s2; out[(size_t)i * 3 + 1] = d[3] * s0 + d[4] * s1 + d[5] * s2;
             out[(size_t)i * 3 + 2] = d[6] * s0 + d[7] * s1 + d[8] * s2;
             return;
         }
-        const T e0 = r[(size_t)i * 3] - s0, e1 = r[(size_t)i * 3 + 1] - s1, e2 = r[(size_t)i * 3 + 2] - s2;
+        const T e0 = ri0 - s0, e1 = ri1 - s1, e2 = ri2 - s2;
         if (MODE == 0) { out[(size_t)i * 3] = e0; out[(size_t)i * 3 + 1] = e1; out[(size_t)i * 3 + 2] = e2; }
         else {
             const T omega = *omega_ptr;
-            const HT<T>* d = Dinv + (size_t)i * 9;
-            out[(size_t)i * 3] = z[(size_t)i * 3] + omega * (d[0] * e0 + d[1] * e1 + d[2] * e2);
-            out[(size_t)i * 3 + 1] = z[(size_t)i * 3 + 1] + omega * (d[3] * e0 + d[4] * e1 + d[5] * e2);
-            out[(size_t)i * 3 + 2] = z[(size_t)i * 3 + 2] + omega * (d[6] * e0 + d[7] * e1 + d[8] * e2);
+            out[(size_t)i * 3] = zi0 + omega * (d[0] * e0 + d[1] * e1 + d[2] * e2);
+            out[(size_t)i * 3 + 1] = zi1 + omega * (d[3] * e0 + d[4] * e1 + d[5] * e2);
+            out[(size_t)i * 3 + 2] = zi2 + omega * (d[6] * e0 + d[7] * e1 + d[8] * e2);
         }
     }
 }
@@ -324,21 +369,33 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int a = g < n_agg ? g : n_agg - 1;
     T s0 = 0, s1 = 0, s2 = 0;
-    for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += LPR) {
-        const HT<T>* b = Rv + (size_t)rb * 9; const size_t i = (size_t)rcol[rb] * 3;
+    const int p0 = rptr[a], p1 = rptr[a + 1];
+    const bool head = g < n_agg && sub == 0;
+    HT<T> dn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // the next level's diagonal inverse: asked for before the walk, used after it
+    T omega = 0;
+    if (head && dinv_next) {
+        omega = *omega_ptr;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) dn[m] = dinv_next[(size_t)a * 9 + m];
+    }
+    const size_t len = (size_t)(p1 - p0);
+    const HT<T>* base = Rv + (size_t)p0 * 9;          // plane-major within the row (cycle format)
+    for (int rb = p0 + sub; rb < p1; rb += LPR) {
+        const HT<T>* q = base + (rb - p0); const size_t i = (size_t)rcol[rb] * 3;
+        T b[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) b[m] = q[(size_t)m * len];
         T x0 = va[i], x1 = va[i + 1], x2 = va[i + 2];
         if (SUB) { x0 -= vb[i]; x1 -= vb[i + 1]; x2 -= vb[i + 2]; }
         s0 += b[0] * x0 + b[1] * x1 + b[2] * x2; s1 += b[3] * x0 + b[4] * x1 + b[5] * x2; s2 += b[6] * x0 + b[7] * x1 + b[8] * x2;
     }
     s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
-    if (g < n_agg && sub == 0) {
+    if (head) {
         rc[(size_t)a * 3] = s0; rc[(size_t)a * 3 + 1] = s1; rc[(size_t)a * 3 + 2] = s2;
         if (dinv_next) {
-            const T omega = *omega_ptr;
-            const HT<T>* d = dinv_next + (size_t)a * 9;
-            z_next[(size_t)a * 3] = omega * (d[0] * s0 + d[1] * s1 + d[2] * s2);
-            z_next[(size_t)a * 3 + 1] = omega * (d[3] * s0 + d[4] * s1 + d[5] * s2);
-            z_next[(size_t)a * 3 + 2] = omega * (d[6] * s0 + d[7] * s1 + d[8] * s2);
+            z_next[(size_t)a * 3] = omega * (dn[0] * s0 + dn[1] * s1 + dn[2] * s2);
+            z_next[(size_t)a * 3 + 1] = omega * (dn[3] * s0 + dn[4] * s1 + dn[5] * s2);
+            z_next[(size_t)a * 3 + 2] = omega * (dn[6] * s0 + dn[7] * s1 + dn[8] * s2);
         }
     }
 }
@@ -352,25 +409,27 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
-    for (int pb = pptr[i] + sub; pb < pptr[i + 1]; pb += LPR) {
-        const HT<T>* b = P + (size_t)pb * 9; const T* v = e + (size_t)pcol[pb] * 3;
+    const int p0 = pptr[i], p1 = pptr[i + 1];
+    const bool head = g < n && sub == 0;
+    T z0 = 0, z1 = 0, z2 = 0;                          // the entry this row adds to: read before the walk
+    if (head) { z0 = z[(size_t)i * zs]; z1 = z[(size_t)i * zs + 1]; z2 = z[(size_t)i * zs + 2]; }
+    const size_t len = (size_t)(p1 - p0);
+    const HT<T>* base = P + (size_t)p0 * 9;           // plane-major within the row (cycle format)
+    for (int pb = p0 + sub; pb < p1; pb += LPR) {
+        const HT<T>* q = base + (pb - p0); const T* v = e + (size_t)pcol[pb] * 3;
+        T b[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) b[m] = q[(size_t)m * len];
         const T v0 = v[0], v1 = v[1], v2 = v[2];
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
     s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
-    if (g < n && sub == 0) { z[(size_t)i * zs] += s0; z[(size_t)i * zs + 1] += s1; z[(size_t)i * zs + 2] += s2; }
+    if (head) { z[(size_t)i * zs] = z0 + s0; z[(size_t)i * zs + 1] = z1 + s1; z[(size_t)i * zs + 2] = z2 + s2; }
 }
 
 // Bottom of the V-cycle in ONE workgroup of 1024 threads: restrict the last explicit level's residual
 // (n <= 224 rows) to the dense level (<= 28 aggregates, 32 lanes each), apply the dense inverse,
 // prolong the correction back (4 lanes per row).
-// A single workgroup pays every dependent memory round trip in full (nothing else hides it), so everything that does
-// not depend on an earlier phase — the rows of the dense inverse, the prolongator blocks and their columns — is
-// requested at the top, together with the restriction's own operands: the three phases then cost one trip to memory
-// plus two LDS hand-overs instead of three trips (12.8 -> ~6 us at 100k poses).
-constexpr int kTailRowsPerWave = (kDenseMax + 15) / 16;      // dense rows per wavefront (16 wavefronts)
-constexpr int kTailColsPerLane = (kDenseMax + 63) / 64;      // columns per lane
-constexpr int kTailPBlocks = 3;                              // prolongator blocks per lane kept in registers (more: loaded late)
 template <typename T>
 __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
                                                                const HT<T>* __restrict__ Rv, const int* __restrict__ pptr,
@@ -378,32 +437,6 @@ __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg,
                                                                const T* __restrict__ inv, T* __restrict__ z, const CgState<T>* __restrict__ st) {
     if (st->done) return;
     __shared__ T rc[kDenseMax], zc_[kDenseMax];
-    const int nd = n_agg * 3;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // ---- requests that depend on nothing computed here
-    T iv[kTailRowsPerWave][kTailColsPerLane];
-#pragma unroll
-    for (int a = 0; a < kTailRowsPerWave; ++a)
-#pragma unroll
-        for (int b = 0; b < kTailColsPerLane; ++b) {
-            const int i = wave + 16 * a, j = lane + 64 * b;
-            iv[a][b] = (i < nd && j < nd) ? inv[(size_t)i * nd + j] : T(0);
-        }
-    const int pi = threadIdx.x / 4, psub = threadIdx.x % 4;
-    int pb0 = 0, pb1 = 0;
-    if (pi < n) { pb0 = pptr[pi] + psub; pb1 = pptr[pi + 1]; }
-    HT<T> pblk[kTailPBlocks][9]; int pc[kTailPBlocks];
-#pragma unroll
-    for (int u = 0; u < kTailPBlocks; ++u) {
-        const int pb = pb0 + 4 * u;
-        pc[u] = -1;
-        if (pi < n && pb < pb1) {
-            pc[u] = pcol[pb];
-#pragma unroll
-            for (int m = 0; m < 9; ++m) pblk[u][m] = P[(size_t)pb * 9 + m];
-        }
-    }
-    // ---- restriction
     {
         const int a = threadIdx.x / 32, sub = threadIdx.x % 32;
         T s0 = 0, s1 = 0, s2 = 0;
@@ -417,34 +450,19 @@ __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg,
         if (a < n_agg && sub == 0) { rc[3 * a] = s0; rc[3 * a + 1] = s1; rc[3 * a + 2] = s2; }
     }
     __syncthreads();
-    // ---- dense inverse times rc: a wavefront per row, lanes over the columns
-#pragma unroll
-    for (int a = 0; a < kTailRowsPerWave; ++a) {
-        const int i = wave + 16 * a;
-        T s = 0;
-#pragma unroll
-        for (int b = 0; b < kTailColsPerLane; ++b) { const int j = lane + 64 * b; if (j < nd) s += iv[a][b] * rc[j]; }
-        s = wave_sum<T>(s);
-        if (i < nd && lane == 0) zc_[i] = s;
-    }
+    const int nd = n_agg * 3;
+    if ((int)threadIdx.x < nd) { T s = 0; for (int j = 0; j < nd; ++j) s += inv[(size_t)threadIdx.x * nd + j] * rc[j]; zc_[threadIdx.x] = s; }
     __syncthreads();
-    // ---- prolongation
     {
+        const int i = threadIdx.x / 4, sub = threadIdx.x % 4;
         T s0 = 0, s1 = 0, s2 = 0;
-        if (pi < n) {
-#pragma unroll
-            for (int u = 0; u < kTailPBlocks; ++u)
-                if (pc[u] >= 0) {
-                    const T* v = zc_ + pc[u] * 3; const HT<T>* b = pblk[u];
-                    s0 += b[0] * v[0] + b[1] * v[1] + b[2] * v[2]; s1 += b[3] * v[0] + b[4] * v[1] + b[5] * v[2]; s2 += b[6] * v[0] + b[7] * v[1] + b[8] * v[2];
-                }
-            for (int pb = pb0 + 4 * kTailPBlocks; pb < pb1; pb += 4) {
+        if (i < n)
+            for (int pb = pptr[i] + sub; pb < pptr[i + 1]; pb += 4) {
                 const HT<T>* b = P + (size_t)pb * 9; const T* v = zc_ + pcol[pb] * 3;
                 s0 += b[0] * v[0] + b[1] * v[1] + b[2] * v[2]; s1 += b[3] * v[0] + b[4] * v[1] + b[5] * v[2]; s2 += b[6] * v[0] + b[7] * v[1] + b[8] * v[2];
             }
-        }
         s0 = group_sum<T, 4>(s0); s1 = group_sum<T, 4>(s1); s2 = group_sum<T, 4>(s2);
-        if (pi < n && psub == 0) { z[(size_t)pi * 3] += s0; z[(size_t)pi * 3 + 1] += s1; z[(size_t)pi * 3 + 2] += s2; }
+        if (i < n && sub == 0) { z[(size_t)i * 3] += s0; z[(size_t)i * 3 + 1] += s1; z[(size_t)i * 3 + 2] += s2; }
     }
 }
 

@@ -118,6 +118,7 @@ template <typename T> struct DevLevel {      // device copy of one AmgLevel (hos
     using H = HT<T>;                              // hierarchy storage type (tsgo_amg_kernels.h)
     T* rel = nullptr;
     H *A = nullptr, *Dinv = nullptr, *P = nullptr, *Tv = nullptr, *Rv = nullptr;
+    H *Apm = nullptr, *Ppm = nullptr, *Rpm = nullptr;       // cycle format: the same blocks, plane-major within each row (tsgo_amg_kernels.h)
     T *r = nullptr, *z = nullptr, *res = nullptr, *z2 = nullptr;
 };
 
@@ -337,7 +338,10 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&D.P, (size_t)D.nnzP * 9)) return rc;
         if (int rc = dalloc(&D.Rv, (size_t)D.nnzP * 9)) return rc;
         if (int rc = dalloc(&D.Tv, (size_t)D.nnzT * 9)) return rc;
+        if (int rc = dalloc(&D.Ppm, (size_t)D.nnzP * 9)) return rc;
+        if (int rc = dalloc(&D.Rpm, (size_t)D.nnzP * 9)) return rc;
         if (l > 0) {
+            if (int rc = dalloc(&D.Apm, (size_t)D.nnzA * 9)) return rc;
             if (int rc = dalloc(&D.r, (size_t)D.n * 3)) return rc;
             if (int rc = dalloc(&D.z, (size_t)D.n * 3)) return rc;
             if (int rc = dalloc(&D.res, (size_t)D.n * 3)) return rc;
@@ -629,27 +633,45 @@ template <typename T> struct Engine : IEngine {
             else if (L.pairs_A > kMediumPairList) hipLaunchKernelGGL((k_pair_gemm_wave<T, 1, 8>), dim3(grid_for(L.n_upper, 8)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
             else hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.n_upper + kPairBlocksPerWave - 1) / kPairBlocksPerWave, 64)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
             hipLaunchKernelGGL((k_mirror_blocks<T>), dim3(grid_for(L.nnzNext, 9)), dim3(kBlock), 0, stream, L.nnzNext, (const int*)L.as_mirror, Anext);
+            // cycle format of what the V-cycle reads on this level (level 0's matrix is only read by the setup)
+            hipLaunchKernelGGL((k_to_planes<T>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, (const int*)L.P_ptr, (const H*)L.P, L.Ppm);
+            hipLaunchKernelGGL((k_to_planes<T>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, (const int*)L.R_ptr, (const H*)L.Rv, L.Rpm);
+            if (l + 1 < lv.size()) hipLaunchKernelGGL((k_to_planes<T>), dim3(grid_for(lv[l + 1].n, 8)), dim3(kBlock), 0, stream, lv[l + 1].n, (const int*)lv[l + 1].A_ptr, (const H*)lv[l + 1].A, lv[l + 1].Apm);
         }
         hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kDenseThreads), 0, stream, nb_last, last_ptr, last_col, (const H*)A_last, inv_last);
         return 0;
     }
 
-    static int lanes_for(double avg_row) { return avg_row <= 4 ? 4 : (avg_row <= 12 ? 8 : (avg_row <= 40 ? 32 : 64)); }
+    static int lanes_for(double avg_row) {
+        static const int shift = getenv("TSGO_LPR_SHIFT") ? atoi(getenv("TSGO_LPR_SHIFT")) : 0;      // research: fewer lanes per row
+        const int l = avg_row <= 4 ? 4 : (avg_row <= 12 ? 8 : (avg_row <= 40 ? 32 : 64));
+        return std::max(4, l >> shift);
+    }
+    // Block-row sweeps (k_bcsr_residual): on the big levels (thousands of rows: every wave slot of the device is taken more
+    // than once) a lane should carry two to four blocks, not one — 16 lanes per row at 28 and at 67 blocks per row measured
+    // 8.7 / 5.6 us against 9.3 / 6.2 us with 32 / 64 lanes; the small levels are one wave round either way and want the
+    // shortest chain, i.e. many lanes (profiles/r02h_lanes_per_row.txt).
+    static int lanes_for_sweep(double avg_row, int n_rows) {
+        if (n_rows >= 4096 && avg_row > 12) return 16;
+        return lanes_for(avg_row);
+    }
 #define LAUNCH_LPR(LPR, KERNEL, EXTRA, n_rows, ...)                                                                      \
     do {                                                                                                                 \
         switch (LPR) {                                                                                                   \
             case 4: hipLaunchKernelGGL((KERNEL<T, 4, EXTRA>), dim3(grid_for(n_rows, 4)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
             case 8: hipLaunchKernelGGL((KERNEL<T, 8, EXTRA>), dim3(grid_for(n_rows, 8)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
+            case 16: hipLaunchKernelGGL((KERNEL<T, 16, EXTRA>), dim3(grid_for(n_rows, 16)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
             case 32: hipLaunchKernelGGL((KERNEL<T, 32, EXTRA>), dim3(grid_for(n_rows, 32)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
             default: hipLaunchKernelGGL((KERNEL<T, 64, EXTRA>), dim3(grid_for(n_rows, 64)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
         }                                                                                                                \
     } while (0)
     void launch_prolong(DevLevel<T>& L, const T* e, T* z, int zs, const CgState<T>* s) {
         switch (lanes_for((double)L.nnzP / std::max(1, L.n))) {
-            case 4: hipLaunchKernelGGL((k_prolong_add<T, 4>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.P, e, z, zs, s); break;
-            case 8: hipLaunchKernelGGL((k_prolong_add<T, 8>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.P, e, z, zs, s); break;
-            case 32: hipLaunchKernelGGL((k_prolong_add<T, 32>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.P, e, z, zs, s); break;
-            default: hipLaunchKernelGGL((k_prolong_add<T, 64>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.P, e, z, zs, s); break;
+            case 4: hipLaunchKernelGGL((k_prolong_add<T, 4>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
+            case 8: hipLaunchKernelGGL((k_prolong_add<T, 8>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
+            case 16: hipLaunchKernelGGL((k_prolong_add<T, 16>), dim3(grid_for(L.n, 16)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
+            case 32: hipLaunchKernelGGL((k_prolong_add<T, 32>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
+            default: hipLaunchKernelGGL((k_prolong_add<T, 64>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
         }
     }
 
@@ -665,7 +687,13 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL((k_seed_vector<T>), dim3(grid_for(n3)), dim3(kBlock), 0, stream, n3, a);
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
             for (int it = 0; it < kRhoSteps; ++it) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 2, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]);
+                switch (lprA) {     // the block-indexed matrix (PM = 0): level 0 has no cycle-format copy
+                    case 4: hipLaunchKernelGGL((k_bcsr_residual<T, 4, 2, 0>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                    case 16: hipLaunchKernelGGL((k_bcsr_residual<T, 16, 2, 0>), dim3(grid_for(L.n, 16)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                    case 8: hipLaunchKernelGGL((k_bcsr_residual<T, 8, 2, 0>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                    case 32: hipLaunchKernelGGL((k_bcsr_residual<T, 32, 2, 0>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                    default: hipLaunchKernelGGL((k_bcsr_residual<T, 64, 2, 0>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                }
                 std::swap(a, b);
             }
             // a = v_K, b = v_{K-1}
@@ -701,23 +729,23 @@ template <typename T> struct Engine : IEngine {
         {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv, (const T*)r, (const T*)sbuf, lv[1].r, (const H*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
+            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rpm, (const T*)r, (const T*)sbuf, lv[1].r, (const H*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
         }
         // coarse levels: V(nu,nu) with nu = coarse_sweeps block-Jacobi sweeps (the first pre-sweep comes fused
         // with the restriction above).  The current iterate alternates between L.z and L.z2; it ends in L.z2.
         for (size_t l = 1; l < nl; ++l) {
             DevLevel<T>& L = lv[l];
             const int nu = nu_at(l);
-            const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
+            const int lprA = lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n);
             T* cur = L.z; T* oth = L.z2;
             for (int sw = 1; sw < nu; ++sw) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, oth, (const T*)(omega_dev + l), s);
+                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, oth, (const T*)(omega_dev + l), s);
                 std::swap(cur, oth);
             }
-            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, L.res, (const T*)(omega_dev + l), s);
+            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, L.res, (const T*)(omega_dev + l), s);
             if (l + 1 < nl) {
                 const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const H*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
+                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rpm, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const H*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
             }
         }
         // iterate of level l after the down pass: L.z when nu is odd, L.z2 when even
@@ -729,13 +757,13 @@ template <typename T> struct Engine : IEngine {
                                (const T*)L.res, (const T*)inv_last, down_iter(L, nu_at(nl - 1)), s);
         } else if (nl > 1) {   // a last explicit level too long for the one-workgroup kernel (4 lanes per row): the same three steps as launches
             DevLevel<T>& L = lv[nl - 1];
-            hipLaunchKernelGGL((k_restrict<T, 8, 0>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv,
+            hipLaunchKernelGGL((k_restrict<T, 8, 0>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rpm,
                                (const T*)L.res, (const T*)L.res, r_last, (const H*)nullptr, (T*)nullptr, (const T*)one_dev, s);
             hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
             launch_prolong(L, z_last, down_iter(L, nu_at(nl - 1)), 3, s);
         } else {        // only level 0 above the dense level: residual r - S z is restricted from (r, sbuf)
             DevLevel<T>& L = lv[0];
-            hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv,
+            hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rpm,
                                (const T*)r, (const T*)sbuf, r_last, (const H*)nullptr, (T*)nullptr, (const T*)one_dev, s);
             hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
         }
@@ -744,9 +772,9 @@ template <typename T> struct Engine : IEngine {
             const int nu = nu_at(l);
             T* cur = down_iter(L, nu); T* oth = down_other(L, nu);
             if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, cur, 3, s);
-            const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
+            const int lprA = lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n);
             for (int sw = 0; sw < nu; ++sw) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, oth, (const T*)(omega_dev + l), s);
+                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, oth, (const T*)(omega_dev + l), s);
                 std::swap(cur, oth);
             }
             // nu post-sweeps after nu-1 pre-swaps: the result sits in L.z2 for every nu (odd+odd / even+even swaps)
@@ -1086,12 +1114,12 @@ template <typename T> struct Engine : IEngine {
         int n = 0;
         for (size_t l = 1; l < lv.size() && n < cap; ++l, ++n) {
             DevLevel<T>& L = lv[l];
-            const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
+            const int lprA = lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n);
             for (int pass = 0; pass < 2; ++pass) {
                 const int m = pass == 0 ? 3 : reps;
                 HIP_OK(hipEventRecord(ev[0], stream));
                 for (int k = 0; k < m; ++k)
-                    LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)L.r, (const T*)L.z, (const H*)L.Dinv, L.z2, (const T*)(omega_dev + l), (const CgState<T>*)st[0]);
+                    LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)L.r, (const T*)L.z, (const H*)L.Dinv, L.z2, (const T*)(omega_dev + l), (const CgState<T>*)st[0]);
                 HIP_OK(hipEventRecord(ev[1], stream));
                 HIP_OK(hipEventSynchronize(ev[1]));
                 if (pass == 1) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[1])); out[n].us_per_sweep = 1e3 * ms / m; }

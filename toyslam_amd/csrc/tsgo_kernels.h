@@ -386,6 +386,15 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
         const int ic = valid ? i : tb.n_vertices - 1;
         const T* zr = zc + (size_t)ic * kPoseRec;
         const T v0 = zr[0], v1 = zr[1], v2 = zr[2], c = zr[3], s = zr[4];
+        // the pose's own diagonal block and residual entry are used at the very end: asked for first
+        const bool head = valid && (lane % G) == 0;
+        const bool own = head && i >= pose_first && i < pose_last;
+        T dpi[6] = {0, 0, 0, 0, 0, 0}, rv0 = 0, rv1 = 0, rv2 = 0;
+        if (own) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) dpi[m] = dp[(size_t)i * 6 + m];
+        }
+        if (head && rvec) { rv0 = rvec[(size_t)i * 3]; rv1 = rvec[(size_t)i * 3 + 1]; rv2 = rvec[(size_t)i * 3 + 2]; }
         T acc0 = 0, acc1 = 0, acc2 = 0;
         {
             const size_t S = tb.slots;
@@ -419,16 +428,16 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
         }
         acc0 = group_sum<T, G>(acc0); acc1 = group_sum<T, G>(acc1); acc2 = group_sum<T, G>(acc2);
         o0 = group_sum<T, G>(o0); o1 = group_sum<T, G>(o1); o2 = group_sum<T, G>(o2);
-        if (valid && (lane % G) == 0) {
+        if (head) {
             o0 += c * acc0 - s * acc1; o1 += s * acc0 + c * acc1; o2 -= acc2;
-            if (i >= pose_first && i < pose_last) {
+            if (own) {
                 T d0, d1, d2;
-                sym3_mul<T>(dp + (size_t)i * 6, v0, v1, v2, d0, d1, d2);
+                sym3_mul<T>(dpi, v0, v1, v2, d0, d1, d2);
                 o0 += d0; o1 += d1; o2 += d2;
             }
             out[(size_t)i * 3] = o0; out[(size_t)i * 3 + 1] = o1; out[(size_t)i * 3 + 2] = o2;
             dot = o0 * v0 + o1 * v1 + o2 * v2;
-            if (rvec) rz = rvec[(size_t)i * 3] * v0 + rvec[(size_t)i * 3 + 1] * v1 + rvec[(size_t)i * 3 + 2] * v2;
+            if (rvec) rz = rv0 * v0 + rv1 * v1 + rv2 * v2;
         }
     }
     const T total = block_sum<T>(dot, red);

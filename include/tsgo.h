@@ -65,6 +65,12 @@ typedef struct tsgo_config {
     int32_t warm_start;      /* 0: PCG starts from zero.  1: from (1 - step) * the previous Gauss-Newton iteration's pose delta (the
                                 un-taken remainder of the last step).  2 (default): from the third solve on, extrapolated with the
                                 delta before that as well, (1 - step) * (2 d1 - (1 - step) d2).  Same answer to pcg_rel_tol. */
+    int32_t rules;           /* 0 (default): the loop of the C++ server, remote/optimizer/OptimizerCpu.h:80-180 (fixed step 0.2, plateau /
+                                short-step / getting-worse stops, b untouched at fixed vertices).  1: the loop of the reference's in-process
+                                Python optimizer, python/optimizer/graph_optimizer.py:20-92 — Levenberg-Marquardt-style damping H + lambda I
+                                (lambda from 1e-3, x1.1 when chi^2 rose, /1.1 otherwise, within [1e-6, 10]; the `lambdaVal` the C++
+                                declares and never uses, OptimizerCpu.h:70), step `lr`, b zeroed at fixed vertices, stop on ||lr dx|| < 1e-3 only. */
+    double lr;               /* rules = 1: the step scale `lr` of GraphOptimizer.optimize(iterations, lr) (slam_main.py passes 0.2); ignored by rules = 0 */
     int32_t reuse_structure; /* 1 (default): tsgo_set_graph with the SAME vertex ids/types, edge list and fixed list as the graph the
                                 handle already holds only refills estimates, measurements and weights (the reference re-creates
                                 everything per message, remote/app/ConnectionHandler.h:18-21); 0: always rebuild.  Same results. */
@@ -83,6 +89,7 @@ typedef struct tsgo_stats {
     double ms_setup;                     /* tsgo_set_graph: host layout build + upload, or the refill when the structure was reused */
     int32_t structure_reused;            /* 1 when the last tsgo_set_graph found the same structure and only refilled values */
     int32_t reserved;
+    double lambda_last;                  /* rules = 1: the damping used by the last iteration */
     int64_t n_pose, n_lm, n_odom_edges, n_lm_edges;
     int64_t pcg_iters_total;
     int32_t pcg_fallbacks;               /* solves repeated with block-Jacobi after a multigrid breakdown */

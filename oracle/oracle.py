@@ -56,7 +56,7 @@ def lib():
                                                   f64p, f64p, i32p]
         L.oracle_sparse_optimize.argtypes = _GRAPH + [f64p, C.c_int, C.c_double, C.c_int, C.c_int, C.c_int, C.c_int,
                                                       ALLREDUCE_FN, C.c_void_p, f64p, i32p, i32p, i32p, f64p,
-                                                      f64p, f64p]
+                                                      f64p, f64p, C.c_int, C.c_double]
         L.oracle_set_threads.argtypes = [C.c_int]
         L.oracle_set_threads.restype = None
         L.oracle_set_threads(default_threads())
@@ -179,13 +179,14 @@ def sparse_step(g, pcg_tol=1e-12, max_cg=100000, rank=0, world=1, allreduce=None
     return dict(delta=d, chi2=float(chi[0]), cg_iters=int(it[0]))
 
 
-def sparse_optimize(g, iterations, pcg_tol=1e-12, max_cg=100000, rank=0, world=1, allreduce=None, precond="jacobi"):
-    """Full GN loop by the sparse CPU twin with the reference's stop rules."""
+def sparse_optimize(g, iterations, pcg_tol=1e-12, max_cg=100000, rank=0, world=1, allreduce=None, precond="jacobi", rules="cpp", lr=0.2):
+    """Full GN loop by the sparse CPU twin with the reference's stop rules (rules="python": the loop of the reference's
+    in-process Python optimizer instead — lambda * I, step lr)."""
     out = np.zeros_like(g.v_pos); chi2 = np.zeros(max(iterations, 1)); cg = np.zeros(max(iterations, 1), np.int32)
     ir = np.zeros(1, np.int32); sr = np.zeros(1, np.int32); dn = np.zeros(1); tl = np.zeros(1); ts = np.zeros(1)
     h = _hook(allreduce)
     rc = lib().oracle_sparse_optimize(*g.args(), out, iterations, pcg_tol, max_cg, PRECOND[precond], rank, world, h, None, chi2, ir, sr,
-                                      cg, dn, tl, ts)
+                                      cg, dn, tl, ts, {"cpp": 0, "python": 1}[rules], float(lr))
     if rc:
         raise RuntimeError("oracle_sparse_optimize rc=%d" % rc)
     n = int(ir[0])

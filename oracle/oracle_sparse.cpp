@@ -47,6 +47,8 @@ struct Twin {
     double chi2 = 0;
     std::vector<double> gscratch;
     bool use_amg = false;
+    double lambda = 0; bool zero_fixed = false;     // the Python optimizer's rules (graph_optimizer.py:42,150), as Engine::launch_lin; 0 / false: cpu eigen
+    double step = tsgo::kStepScale;
     int n_lin = 0;
     int hier_age = -1, iters_fresh = 0, iters_last = 0;   // hierarchy refresh policy, as Engine::do_linearize (tsgo_hip.hip)
     tsgo::AmgSym amg;
@@ -169,7 +171,7 @@ struct Twin {
         const tsgo::SellTable& tb = pr.by_lm; const size_t S = tb.slots();
         #pragma omp parallel for schedule(static)
         for (int l = 0; l < L; ++l) {
-            double dxx = pr.gauge_l[l], dxy = 0, dyy = pr.gauge_l[l], g0 = 0, g1 = 0;
+            double dxx = pr.gauge_l[l] + lambda, dxy = 0, dyy = pr.gauge_l[l] + lambda, g0 = 0, g1 = 0;
             const double lx = ls[2 * (size_t)l], ly = ls[2 * (size_t)l + 1];
             for_slots(tb, l, [&](size_t k) {
                 const double* q4 = &ps[4 * (size_t)tb.idx[k]];
@@ -181,6 +183,7 @@ struct Twin {
                 const double f0 = o.a0 * o.e0, f1 = o.a1 * o.e1;          // g_l = -B^T W e = -R (f0, f1)
                 g0 -= c * f0 - sn * f1; g1 -= sn * f0 + c * f1;
             });
+            if (zero_fixed && pr.gauge_l[l] > 0) { g0 = 0; g1 = 0; }
             double ixx, ixy, iyy; tsgo::inv_sym2(dxx, dxy, dyy, ixx, ixy, iyy);
             dlinv[3 * (size_t)l] = ixx; dlinv[3 * (size_t)l + 1] = ixy; dlinv[3 * (size_t)l + 2] = iyy;
             u[2 * (size_t)l] = ixx * g0 + ixy * g1; u[2 * (size_t)l + 1] = ixy * g0 + iyy * g1;
@@ -248,6 +251,7 @@ struct Twin {
                 for (int m = 0; m < 3; ++m) o18[6 + m] += sg * o.a[m] * o.e[m];
                 if (!second) chi += o.rho;
             });
+            if (zero_fixed && pr.gauge_p[i] > 0) { o18[6] = 0; o18[7] = 0; o18[8] = 0; }
         }
         part[(size_t)P * 18] = chi;
     }
@@ -334,12 +338,12 @@ struct Twin {
     double linearize(const std::vector<double>* warm = nullptr) {
         lin_lm(); lin_pose();
         // gauge of owned poses goes into the partial so that it is summed exactly once across shards
-        for (int i = pr.pose_first; i < pr.pose_last; ++i) { part[(size_t)i * 18] += pr.gauge_p[i]; part[(size_t)i * 18 + 3] += pr.gauge_p[i]; part[(size_t)i * 18 + 5] += pr.gauge_p[i]; }
+        for (int i = pr.pose_first; i < pr.pose_last; ++i) { const double ga = pr.gauge_p[i] + lambda; part[(size_t)i * 18] += ga; part[(size_t)i * 18 + 3] += ga; part[(size_t)i * 18 + 5] += ga; }
         allreduce(part.data(), (int64_t)part.size());
         double g0 = finalize();
         double scale = 1;
         if (warm && warm->size() == x.size()) {
-            for (size_t k = 0; k < x.size(); ++k) x[k] = (1.0 - tsgo::kStepScale) * (*warm)[k];
+            for (size_t k = 0; k < x.size(); ++k) x[k] = (1.0 - step) * (*warm)[k];
             std::vector<double> buf((size_t)P * 3 + 1);
             schur_lm(x);
             buf[(size_t)P * 3] = schur_pose(x, buf);
@@ -442,14 +446,14 @@ struct Twin {
         for (int i = 0; i < P; ++i) {
             const double* d = &x[3 * (size_t)i];
             n2 += d[0] * d[0] + d[1] * d[1] + d[2] * d[2];
-            ps[4 * (size_t)i] += tsgo::kStepScale * d[0]; ps[4 * (size_t)i + 1] += tsgo::kStepScale * d[1];
-            const double nt = std::atan2(ps[4 * (size_t)i + 3], ps[4 * (size_t)i + 2]) + tsgo::kStepScale * d[2];
+            ps[4 * (size_t)i] += step * d[0]; ps[4 * (size_t)i + 1] += step * d[1];
+            const double nt = std::atan2(ps[4 * (size_t)i + 3], ps[4 * (size_t)i + 2]) + step * d[2];
             th[i] = nt; ps[4 * (size_t)i + 2] = std::cos(nt); ps[4 * (size_t)i + 3] = std::sin(nt);
         }
         double l2 = 0;
         for (int l = 0; l < L; ++l) {
             l2 += dl[2 * (size_t)l] * dl[2 * (size_t)l] + dl[2 * (size_t)l + 1] * dl[2 * (size_t)l + 1];
-            ls[2 * (size_t)l] += tsgo::kStepScale * dl[2 * (size_t)l]; ls[2 * (size_t)l + 1] += tsgo::kStepScale * dl[2 * (size_t)l + 1];
+            ls[2 * (size_t)l] += step * dl[2 * (size_t)l]; ls[2 * (size_t)l + 1] += step * dl[2 * (size_t)l + 1];
         }
         // landmark deltas are shard-local: sum their squared norm across shards
         double b[1] = {l2}; allreduce(b, 1);
@@ -506,10 +510,14 @@ int oracle_sparse_step(GRAPH_ARGS, double pcg_tol, int max_cg, int precond, int 
 
 // Full loop with the reference's rules (OptimizerCpu.h:80-180).  v_pos_out: 3 per vertex (landmarks of
 // other shards are left at their input value).  stop_reason as in oracle_dense.cpp.
+// rules 0: OptimizerCpu.h:80-180.  rules 1: graph_optimizer.py:20-92 (lambda * I, step lr, b zeroed at fixed vertices, stop on ||lr dx||).
 int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double pcg_tol, int max_cg, int precond, int rank, int world,
                            allreduce_fn hook, void* ctx, double* chi2_trace, int* iters_run, int* stop_reason,
-                           int* cg_trace, double* last_delta_norm, double* seconds_lin, double* seconds_solve) {
+                           int* cg_trace, double* last_delta_norm, double* seconds_lin, double* seconds_solve, int rules, double lr) {
     Twin tw; tw.hook = hook; tw.hook_ctx = ctx;
+    const bool py = rules == 1;
+    if (py) { tw.zero_fixed = true; tw.step = lr; }
+    double lam = 1e-3;
     const tsgo_graph g = make_view(GRAPH_PASS);
     if (!tw.init(g, rank, world).empty()) return -2;
     if (precond == 1 && !tw.enable_amg(g).empty()) return -5;
@@ -527,21 +535,28 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
         std::vector<double> xw;
         if (it > 1 && ext != 0.0 && xprev2.size() == xprev.size()) {     // x0 = 0.8 (d1 + ext * (d1 - 0.8 d2)) after the 0.8 scaling inside linearize()
             xw.resize(xprev.size());
-            for (size_t k = 0; k < xw.size(); ++k) xw[k] = xprev[k] + ext * (xprev[k] - (1.0 - tsgo::kStepScale) * xprev2[k]);
+            for (size_t k = 0; k < xw.size(); ++k) xw[k] = xprev[k] + ext * (xprev[k] - (1.0 - tw.step) * xprev2[k]);
         }
-        const double gamma0 = tw.linearize(it > 0 && !cold ? (xw.empty() ? &xprev : &xw) : nullptr);
+        const std::vector<double>* warm = it > 0 && !cold ? (xw.empty() ? &xprev : &xw) : nullptr;
+        double gamma0;
+        if (py) {          // as Engine::optimize: linearise with the lambda a non-increasing chi^2 gives, repeat when it did rise
+            tw.lambda = std::max(lam / 1.1, 1e-6);
+            gamma0 = tw.linearize(warm);
+            if (prevErr > -1 && tw.chi2 > prevErr) { tw.lambda = std::min(lam * 1.1, 1e1); gamma0 = tw.linearize(warm); }
+            lam = tw.lambda;
+        } else gamma0 = tw.linearize(warm);
         double t1 = now(); if (seconds_lin) *seconds_lin += t1 - t0;
         const double err = tw.chi2;
         chi2_trace[it] = err; *iters_run = it + 1;
-        if (prevErr > 0 && err > prevErr) { if (++penalty > 2) { *stop_reason = 1; break; } } else penalty = 0;
+        if (!py) { if (prevErr > 0 && err > prevErr) { if (++penalty > 2) { *stop_reason = 1; break; } } else penalty = 0; }
         bool ok; cg_trace[it] = tw.solve_with_fallback(gamma0, pcg_tol, max_cg, &ok);
         if (!ok) { *stop_reason = 4; break; }
         xprev2 = xprev; xprev = tw.x;
         std::vector<double> dl; tw.backsub(dl);
-        const double nrm = tw.update(dl);
+        const double nrm = (py ? lr : 1.0) * tw.update(dl);
         if (seconds_solve) *seconds_solve += now() - t1;
         *last_delta_norm = nrm;
-        if (std::fabs(err - prevErr) < tsgo::kPlateauTol) { *stop_reason = 2; break; }
+        if (!py && std::fabs(err - prevErr) < tsgo::kPlateauTol) { *stop_reason = 2; break; }
         if (nrm < tsgo::kDeltaTol) { *stop_reason = 3; break; }
         prevErr = err;
     }

@@ -242,3 +242,20 @@ def test_sharded_multigrid_lists_partition_the_whole_graphs_lists(world):
         assert list(info.rows) == list(whole.rows) and list(info.blocks) == list(whole.blocks) and list(info.p_blocks) == list(whole.p_blocks)
         pairs += info.schur_contribs; odoms += od.value
     assert pairs == whole.schur_contribs and odoms == od_whole.value and pairs > 0 and odoms > 0
+
+
+def test_twin_python_rules_reproduce_the_reference_python_optimizer():
+    """rules="python": the loop of python/optimizer/graph_optimizer.py:20-92 (lambda * I damping, step lr, b zeroed at fixed
+    vertices).  Pinned by the 10-iteration trajectory the reference's own GraphOptimizer.optimize(10, lr=.2) produced
+    (tests/golden/c1_pyopt.npz) — through the Schur complement and multigrid PCG instead of scipy.linalg.solve."""
+    z = util.load("c1_pyopt.npz")
+    g = util.c1_arrays()
+    for precond in ("amg", "jacobi"):
+        r = oracle.sparse_optimize(util.to_oracle(g), 10, pcg_tol=1e-13, precond=precond, rules="python", lr=0.2)
+        np.testing.assert_allclose(r["chi2"], z["chi2"], rtol=1e-10)
+        assert util.max_vertex_diff(r["v_pos"], z["v_pos"], g.v_type) < 1e-8
+    # lr = 1 (the Python signature's default) against the dense restatement of the same loop
+    rd = oracle.optimize(util.to_oracle(g), 6, mode="python", solver="chol", lr=1.0)
+    r1 = oracle.sparse_optimize(util.to_oracle(g), 6, pcg_tol=1e-13, precond="amg", rules="python", lr=1.0)
+    assert r1["iters"] == rd["iters"] and r1["stop"] == rd["stop"]
+    np.testing.assert_allclose(r1["chi2"], rd["chi2"], rtol=1e-9)

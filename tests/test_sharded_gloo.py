@@ -21,7 +21,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, n_poses, precond):
+def _worker(rank, world, port, out_dir, n_poses, precond, rules):
     sys.path.insert(0, ROOT)
     torch.set_num_threads(2)      # also sizes the twin's OpenMP loops (same libgomp)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -36,7 +36,7 @@ def _worker(rank, world, port, out_dir, n_poses, precond):
         calls[0] += 1
         dist.all_reduce(torch.from_numpy(buf), op=dist.ReduceOp.SUM)
 
-    r = oracle.sparse_optimize(util.to_oracle(g), 3, pcg_tol=1e-12, rank=rank, world=world, allreduce=allreduce, precond=precond)
+    r = oracle.sparse_optimize(util.to_oracle(g), 3, pcg_tol=1e-12, rank=rank, world=world, allreduce=allreduce, precond=precond, rules=rules, lr=0.5)
     # landmarks are shard-local: owned ones moved, the others still hold their input value
     moved = np.any(r["v_pos"] != g.v_pos, axis=1) & (g.v_type == 1)
     lm = np.where(moved[:, None], r["v_pos"], 0.0)
@@ -49,14 +49,14 @@ def _worker(rank, world, port, out_dir, n_poses, precond):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,precond,n_poses", [(2, "jacobi", 300), (2, "amg", 1500), (3, "amg", 700)])
-def test_sharded_run_across_processes_matches_single_process(tmp_path, world, precond, n_poses):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_poses, precond), nprocs=world, join=True)
+@pytest.mark.parametrize("world,precond,n_poses,rules", [(2, "jacobi", 300, "cpp"), (2, "amg", 1500, "cpp"), (3, "amg", 700, "cpp"), (2, "amg", 600, "python")])
+def test_sharded_run_across_processes_matches_single_process(tmp_path, world, precond, n_poses, rules):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_poses, precond, rules), nprocs=world, join=True)
     from oracle import oracle
     from tests import util
     from toyslam_amd import synth
     g = synth.make(n_poses, 10, loop_closures=30, seed=11)
-    ref = oracle.sparse_optimize(util.to_oracle(g), 3, pcg_tol=1e-12, precond=precond)
+    ref = oracle.sparse_optimize(util.to_oracle(g), 3, pcg_tol=1e-12, precond=precond, rules=rules, lr=0.5)
     outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for o in outs:
         np.testing.assert_allclose(o["chi2"], ref["chi2"], rtol=1e-11)

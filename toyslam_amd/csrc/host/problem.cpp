@@ -192,7 +192,7 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
         if (v < 0) return "fixed vertex id " + std::to_string(g.fixed[i]) + " is unknown";
         if (g.v_type[v] == 0) {
             const int p = pose_internal[cls[v]];
-            if (p >= pr.pose_first && p < pr.pose_last) pr.gauge_p[p] += kGaugeTerm;
+            pr.gauge_p[p] += kGaugeTerm;      // known on every shard (the Python rules zero a fixed pose's gradient everywhere); APPLIED by the owner only
         } else {
             const int c = cls[v];
             if (c >= pr.lm_first && c < pr.lm_last) pr.gauge_l[lm_internal[c - pr.lm_first]] += kGaugeTerm;

@@ -60,7 +60,7 @@ struct Problem {
     std::vector<int> lm_vertex;         // internal (local) landmark -> position
     std::vector<double> pose_xyt;       // 3 per pose
     std::vector<double> lm_xy;          // 2 per owned landmark
-    std::vector<double> gauge_p, gauge_l;   // 1e6 * multiplicity in the fixed list (owned only)
+    std::vector<double> gauge_p, gauge_l;   // 1e6 * multiplicity in the fixed list: every pose (applied by the shard that owns it), owned landmarks
     SellTable by_pose, by_lm, odom;
     int n_vertices = 0;                 // of the input graph
 };

@@ -583,9 +583,14 @@ template <typename T> struct Engine : IEngine {
     }
 
     // ---- launches --------------------------------------------------------------------------------
+    // damping of the current linearisation (rules = 1, graph_optimizer.py:24-43; 0 under the cpu/eigen rules) and the step the update takes
+    double lambda = 0;
+    bool py_rules() const { return cfg.rules == 1; }
+    double step_scale() const { return py_rules() ? cfg.lr : kStepScale; }
     void launch_lin() {
-        if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv);
-        LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18);
+        const int zf = py_rules() ? 1 : 0;
+        if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv, (T)lambda, zf);
+        LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
     }
     void launch_finalize() {
         hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0], (const T*)(amg_on ? omega_dev : one_dev), gscale_dev);
@@ -870,7 +875,7 @@ template <typename T> struct Engine : IEngine {
         // x0 = the un-taken remainder of the previous step, (1 - step) d1 — plus, from the third solve on, the same remainder of
         // what the last step itself added over ITS prediction: with c1 = d1 - (1 - step) d2 the damped iteration repeats
         // d_next ~ (1 - step) (d1 + c1).  Saves another 1-2 iterations per solve (profiles/r02f_warm_start_extrapolation.txt).
-        const T a = (T)(1.0 - kStepScale);
+        const T a = (T)(1.0 - step_scale());
         if (n_prev >= 2 && cfg.warm_start >= 2)
             hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, (T)(2 * a), (const T*)xprev2, (T)(-a * a));
         else
@@ -992,17 +997,33 @@ template <typename T> struct Engine : IEngine {
         const int fallbacks0 = n_fallbacks;
         s.stop_reason = TSGO_STOP_CAP;
         const auto wall0 = std::chrono::steady_clock::now();
+        // rules = 1 (graph_optimizer.py:24-31): lambda starts at 1e-3 on every call
+        const double lam_max = 1e1, lam_min = 1e-6, lam_fac = 1.1;
+        double lam = 1e-3;
+        const double step = step_scale();
         for (int it = 0; it < iterations; ++it) {
             double err = 0; float ms = 0;
             HIP_OK(hipEventRecord(ev[0], stream));
-            if (int rc = do_linearize(&err)) return rc;
+            if (py_rules()) {
+                // lambda follows the chi^2 of THIS linearisation (:41-42), which the linearisation itself needs: it is run with the
+                // value a non-increasing chi^2 gives (the common case) and repeated with the other one when chi^2 did rise
+                lambda = std::max(lam / lam_fac, lam_min);
+                if (int rc = do_linearize(&err)) return rc;
+                if (prevErr > -1 && err > prevErr) { lambda = std::min(lam * lam_fac, lam_max); if (int rc = do_linearize(&err)) return rc; }
+                lam = lambda; s.lambda_last = lam;
+            } else {
+                lambda = 0;
+                if (int rc = do_linearize(&err)) return rc;
+            }
             HIP_OK(hipEventRecord(ev[1], stream));
             if (it < TSGO_MAX_TRACE) s.chi2[it] = err;
             s.chi2_last = err;
             s.iterations_run = it + 1; s.trace_len = std::min(it + 1, TSGO_MAX_TRACE);
-            if (prevErr > 0 && err > prevErr) {                          // OptimizerCpu.h:140-153
-                if (++penalty > 2) { s.stop_reason = TSGO_STOP_WORSE; break; }
-            } else penalty = 0;
+            if (!py_rules()) {
+                if (prevErr > 0 && err > prevErr) {                          // OptimizerCpu.h:140-153
+                    if (++penalty > 2) { s.stop_reason = TSGO_STOP_WORSE; break; }
+                } else penalty = 0;
+            }
             int cg = 0, fail = 0;
             if (int rc = do_solve(&cg, &fail)) return rc;
             HIP_OK(hipEventRecord(ev[2], stream));
@@ -1010,7 +1031,7 @@ template <typename T> struct Engine : IEngine {
             s.pcg_iters_total += cg;
             if (fail == 1) { s.stop_reason = TSGO_STOP_SOLVER; break; }
             double np2 = 0, nl2 = 0;
-            if (int rc = do_backsub_update((T)kStepScale, &np2, &nl2)) return rc;   // :159-165
+            if (int rc = do_backsub_update((T)step, &np2, &nl2)) return rc;   // :159-165 / graph_optimizer.py:66-75
             HIP_OK(hipEventRecord(ev[3], stream));
             HIP_OK(hipEventSynchronize(ev[3]));
             HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[1])); s.ms_linearize += ms;
@@ -1018,20 +1039,22 @@ template <typename T> struct Engine : IEngine {
             HIP_OK(hipEventElapsedTime(&ms, ev[2], ev[3])); s.ms_update += ms;
             nl2_whole = !collective();
             const bool last = it + 1 == iterations;
-            const bool plateau = std::fabs(err - prevErr) < kPlateauTol;
-            if (collective() && (last || plateau || np2 < kDeltaTol * kDeltaTol)) {      // every rank takes this branch or none does
+            const bool plateau = !py_rules() && std::fabs(err - prevErr) < kPlateauTol;
+            // the norm the stop rule looks at: ||delta|| (OptimizerCpu.h:173) or ||lr * dx|| (graph_optimizer.py:66,90)
+            const double norm_scale = py_rules() ? step : 1.0;
+            if (collective() && (last || plateau || norm_scale * norm_scale * np2 < kDeltaTol * kDeltaTol)) {      // every rank takes this branch or none does
                 if (int rc = landmark_norm_allreduce(&nl2)) return rc;
                 nl2_whole = true;
             }
-            s.last_delta_norm = std::sqrt(np2 + nl2);
+            s.last_delta_norm = norm_scale * std::sqrt(np2 + nl2);
             np2_last = np2; nl2_last = nl2;
             if (plateau) { s.stop_reason = TSGO_STOP_PLATEAU; break; }                                  // :167-171
-            if (nl2_whole && s.last_delta_norm < kDeltaTol) { s.stop_reason = TSGO_STOP_CONVERGED; break; }   // :173-177
-            prevErr = err;                                                                              // :179
+            if (nl2_whole && s.last_delta_norm < kDeltaTol) { s.stop_reason = TSGO_STOP_CONVERGED; break; }   // :173-177 / py :90-92
+            prevErr = err;                                                                              // :179 / py :44
         }
         if (!nl2_whole) {             // the loop ended before its last update's landmark norm was summed (worse / solver stop)
             if (int rc = landmark_norm_allreduce(&nl2_last)) return rc;
-            s.last_delta_norm = std::sqrt(np2_last + nl2_last);
+            s.last_delta_norm = (py_rules() ? step_scale() : 1.0) * std::sqrt(np2_last + nl2_last);
         }
         s.pcg_fallbacks = n_fallbacks - fallbacks0;
         s.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
@@ -1161,8 +1184,8 @@ template <typename T> struct Engine : IEngine {
                                            gpart[1], st[0], st[1], minv, r, p, q, x, zc, tol2, 1 << 30, (const T*)one_dev);
                         break;
                     }
-                    case 3: if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv); break;
-                    case 4: LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18); break;
+                    case 3: if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv, (T)lambda, py_rules() ? 1 : 0); break;
+                    case 4: LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, py_rules() ? 1 : 0); break;
                     case 6: if (amg_on) { if (int rc = launch_amg_setup()) return rc; } break;
                     default: if (int rc = launch_iteration(0)) return rc; if (int rc = launch_iteration(1)) return rc; break;
                 }

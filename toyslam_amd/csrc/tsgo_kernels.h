@@ -105,7 +105,7 @@ template <typename T> __device__ __forceinline__ T block_sum_array(const T* a, i
 //   writes: slot planes a0 a1 ppx ppy (lm-major copy), lmrec[l][2..6] = Dl^-1, u
 template <typename T, int G>
 __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restrict__ ps, T* __restrict__ lmrec,
-                                                   const T* __restrict__ gauge_l, T* __restrict__ ninv) {
+                                                   const T* __restrict__ gauge_l, T* __restrict__ ninv, T lambda, int zero_fixed) {
     const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     if (slice >= tb.n_slices) return;
     const int lane = threadIdx.x & 63;
@@ -135,9 +135,12 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restr
     dxx = group_sum<T, G>(dxx); dxy = group_sum<T, G>(dxy); dyy = group_sum<T, G>(dyy);
     g0 = group_sum<T, G>(g0); g1 = group_sum<T, G>(g1);
     if (valid && (lane % G) == 0) {
+        // lambda: the LM-style damping of the reference's Python optimizer (H + lambda I, graph_optimizer.py:42), 0 under the
+        // cpu/eigen rules; zero_fixed: that optimizer also zeroes b at fixed vertices (:150), OptimizerCpu.h does not
         const T ga = gauge_l[l];
+        if (zero_fixed && ga > T(0)) { g0 = 0; g1 = 0; }
         T ixx, ixy, iyy;
-        inv_sym2<T>(dxx + ga, dxy, dyy + ga, ixx, ixy, iyy);
+        inv_sym2<T>(dxx + ga + lambda, dxy, dyy + ga + lambda, ixx, ixy, iyy);
         T* o = lmrec + (size_t)l * kLmRec;
         o[2] = ixx; o[3] = ixy; o[4] = iyy; o[5] = ixx * g0 + ixy * g1; o[6] = ixy * g0 + iyy * g1;
         // compact copy of Dl^-1 for the Schur product's epilogue: 32 B per landmark instead of a 64-B record
@@ -154,7 +157,7 @@ template <typename T, int G>
 __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, const T* __restrict__ ps,
                                                      const T* __restrict__ lmrec, const T* __restrict__ gauge_p,
                                                      int pose_first, int pose_last, T* __restrict__ part,
-                                                     T* __restrict__ chi_part) {
+                                                     T* __restrict__ chi_part, T lambda, int zero_fixed) {
     __shared__ T red[kWavesPerBlock];
     const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
@@ -230,11 +233,15 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
         GS(od0); GS(od1); GS(od2); GS(og0); GS(og1); GS(og2);
 #undef GS
         if (valid && (lane % G) == 0) {
-            const T ga = (i >= pose_first && i < pose_last) ? gauge_p[i] : T(0);
+            // gauge and damping enter once: through the shard that owns the pose
+            const bool own = i >= pose_first && i < pose_last;
+            const T ga = own ? gauge_p[i] + lambda : T(0);
+            const bool fixed_here = zero_fixed && gauge_p[i] > T(0);      // gauge_p holds the owned poses' terms; others see 0 and the owner's partial decides
             T* o = part + (size_t)i * 18;
             o[0] = c * c * sA0 + s * s * sA1 + od0 + ga; o[1] = c * s * (sA0 - sA1); o[3] = s * s * sA0 + c * c * sA1 + od1 + ga;
             o[2] = -(c * sAv0 - s * sAv1); o[4] = -(s * sAv0 + c * sAv1); o[5] = sVV + od2 + ga;
             o[6] = c * ge0 - s * ge1 + og0; o[7] = s * ge0 + c * ge1 + og1; o[8] = -get + og2;
+            if (fixed_here) { o[6] = 0; o[7] = 0; o[8] = 0; }
             o[9] = c * c * K00 - 2 * c * s * K01 + s * s * K11;
             o[10] = c * s * (K00 - K11) + (c * c - s * s) * K01;
             o[12] = s * s * K00 + 2 * c * s * K01 + c * c * K11;

@@ -17,7 +17,7 @@ STOP = {0: "cap", 1: "worse", 2: "plateau", 3: "converged", 4: "solver_failed"}
 class HipOptimizer:
     def __init__(self, device=0, precision=64, pcg_rel_tol=1e-10, pcg_max_iters=20000, lanes_per_pose=0,
                  lanes_per_lm=0, use_graphs=True, rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None,
-                 reuse_structure=None):
+                 reuse_structure=None, rules="cpp", lr=0.2):
         self.lib = _lib.hip_lib()
         cfg = _lib.tsgo_config()
         self.lib.tsgo_default_config(C.byref(cfg))
@@ -31,6 +31,7 @@ class HipOptimizer:
             cfg.warm_start = int(warm_start)
         if reuse_structure is not None:
             cfg.reuse_structure = int(reuse_structure)
+        cfg.rules, cfg.lr = {"cpp": 0, "python": 1}[rules], float(lr)
         self.cfg = cfg
         self.h = C.c_void_p()
         _lib.check(self.lib, self.lib.tsgo_create(C.byref(cfg), C.byref(self.h)), "tsgo_create")
@@ -58,7 +59,7 @@ class HipOptimizer:
         n = st.trace_len
         return dict(iters=st.iterations_run, stop=STOP[st.stop_reason], chi2=np.array(st.chi2[:n]), chi2_last=st.chi2_last,
                     cg_iters=np.array(st.pcg_iters[:n]), delta_norm=st.last_delta_norm, ms_total=st.ms_total,
-                    ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup, structure_reused=bool(st.structure_reused),
+                    ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup, structure_reused=bool(st.structure_reused), lambda_last=st.lambda_last,
                     n_pose=st.n_pose, n_lm=st.n_lm, n_odom_edges=st.n_odom_edges, n_lm_edges=st.n_lm_edges,
                     cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks)
 
@@ -111,10 +112,16 @@ class GraphOptimizer:
         self.last = None
 
     def optimize(self, iterations, lr=0.2):
-        if lr != 0.2:
-            raise ValueError("the remote optimizer's step is fixed at 0.2 (remote/optimizer/OptimizerCpu.h:164)")
+        """rules="cpp" (default): the C++ server's loop, whose step is fixed at 0.2 (remote/optimizer/OptimizerCpu.h:164).
+        rules="python": the reference's own GraphOptimizer.optimize(iterations, lr) — damping lambda*I, any lr."""
+        kw = dict(self.kw)
+        if kw.get("rules", "cpp") == "cpp":
+            if lr != 0.2:
+                raise ValueError("the remote optimizer's step is fixed at 0.2 (remote/optimizer/OptimizerCpu.h:164); pass rules=\"python\" for GraphOptimizer.optimize(iterations, lr)")
+        else:
+            kw["lr"] = lr
         arr = GraphArrays.from_optgraph(self.graph)
-        opt = HipOptimizer(**self.kw)
+        opt = HipOptimizer(**kw)
         try:
             opt.set_graph(arr)
             self.last = opt.optimize(iterations)

@@ -119,6 +119,8 @@ def main():
                        rank=rank if shard else 0, world=world if shard else 1,
                        use_graphs=not ARGS.no_graphs, lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
                        preconditioner=ARGS.precond)
+    if ARGS.force_collective and world == 1:          # research: the sharded code path (eager launches + RCCL calls) with a one-rank communicator
+        opt.comm_init(opt.comm_unique_id())
     if shard:
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -202,8 +204,9 @@ def main():
                        "solver": "implicit-Schur PCG (Chronopoulos-Gear), %s, rel tol %g"
                                  % ("smoothed-aggregation multigrid V(1,1) preconditioner" if amg else "block-Jacobi on the Schur diagonal", ARGS.pcg_tol),
                        "parallelism": ("BASELINE config 4: one graph edge-sharded x%d (landmark ranges), replicated multigrid hierarchy, RCCL all-reduce per Schur product" % world) if shard else
-                                      ("request-parallel: %d independent graphs, one per GPU, no collective" % world if world > 1 else "single GPU"),
-                       "hipgraph": (not ARGS.no_graphs) and not shard},
+                                      ("request-parallel: %d independent graphs, one per GPU, no collective" % world if world > 1 else
+                                       ("single GPU, collective code path forced (one-rank RCCL communicator)" if ARGS.force_collective else "single GPU")),
+                       "hipgraph": (not ARGS.no_graphs) and not shard and not ARGS.force_collective},
             "gn_iters_per_s": ARGS.steps / dt,
             "pcg_iters_per_gn_iter": n_cg,
             "chi2_first_last": [chi2[0], chi2[-1]],
@@ -250,6 +253,8 @@ if __name__ == "__main__":
     ap.add_argument("--request-parallel", dest="request_parallel", action="store_true",
                     help="N > 1: every rank optimises its own graph (weak scaling) instead of sharding ONE graph (BASELINE config 4)")
     ap.add_argument("--shard", action="store_true", help="accepted for compatibility: sharding is the default for N > 1")
+    ap.add_argument("--force-collective", dest="force_collective", action="store_true",
+                    help="N = 1: give the engine a one-rank RCCL communicator so that it takes the sharded code path (eager launches, all-reduce calls)")
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true")
     ap.add_argument("--no-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--no-conv", dest="no_conv", action="store_true", help="skip the 50-iteration convergence run")

@@ -96,6 +96,20 @@ def cpu_baseline(g, threads):
     return out
 
 
+class stdout_to_stderr:
+    """RCCL prints a version banner on STDOUT when a communicator is created; this script's stdout is ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self.saved, 1)
+        os.close(self.saved)
+
+
 def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -110,7 +124,9 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        with stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+            dist.barrier()                           # the communicator (and its banner) is created lazily: now
 
     shard = world > 1 and not ARGS.request_parallel
     g = synth.make_config(ARGS.workload, seed=0 if shard else rank)
@@ -120,13 +136,15 @@ def main():
                        use_graphs=not ARGS.no_graphs, lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
                        preconditioner=ARGS.precond)
     if ARGS.force_collective and world == 1:          # research: the sharded code path (eager launches + RCCL calls) with a one-rank communicator
-        opt.comm_init(opt.comm_unique_id())
+        with stdout_to_stderr():
+            opt.comm_init(opt.comm_unique_id())
     if shard:
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid = torch.tensor(list(opt.comm_unique_id()), dtype=torch.uint8, device="cuda")
-        dist.broadcast(uid, 0)
-        opt.comm_init(bytes(uid.cpu().tolist()))
+        with stdout_to_stderr():
+            uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+            if rank == 0:
+                uid = torch.tensor(list(opt.comm_unique_id()), dtype=torch.uint8, device="cuda")
+            dist.broadcast(uid, 0)
+            opt.comm_init(bytes(uid.cpu().tolist()))
     opt.set_graph(g)
 
     def barrier():

@@ -8,7 +8,7 @@ Never combines --pmc with a trace domain other than --kernel-trace."""
 import csv, glob, json, os, re, statistics, subprocess, sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
-out_dir, tag = sys.argv[1], sys.argv[2]
+out_dir, tag = os.path.abspath(sys.argv[1]), sys.argv[2]          # rocprofv3 runs from /tmp: relative paths would land there
 os.makedirs(out_dir, exist_ok=True)
 cmd = ["python3", os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-conv"]
 os.environ.setdefault("TMPDIR", "/tmp")

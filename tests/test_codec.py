@@ -1,5 +1,6 @@
 """Wire codec (csrc/host/codec.cpp) against bytes produced by the reference's own graph_to_bytes
 (tests/golden/c1_request.bin, tiny_*.npz["request"]) and against an independent reply reader."""
+import os
 import struct
 
 import numpy as np
@@ -130,3 +131,14 @@ def test_optgraph_mirror_round_trip():
     a.write_back(g, a.v_pos + [[0, 0, 0], [1, 0, .1], [0, 1, 0]])
     np.testing.assert_allclose(g.get_vertex(1).position[:2, 2], [2., 2.])
     np.testing.assert_allclose(g.get_vertex(2).position, [3., 5.])
+
+
+def test_mutated_requests_never_crash_the_decoder():
+    """tools/fuzz_codec.py (truncations, bit flips, corrupted count words, trailing garbage): every mutated request is either
+    rejected with an error or decoded and re-encoded; tools/sanitize_host.sh runs the same under ASan + UBSan."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_codec.py"), "600"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "no crash" in out.stdout

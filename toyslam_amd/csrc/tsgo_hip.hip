@@ -806,7 +806,10 @@ template <typename T> struct Engine : IEngine {
         }
         return 0;
     }
-    int chunk() const { return amg_on ? kChunkAmg : kChunk; }
+    int chunk() const {
+        static const int env = getenv("TSGO_CHUNK_AMG") ? std::max(2, atoi(getenv("TSGO_CHUNK_AMG")) & ~1) : 0;     // research: iterations per captured graph (even)
+        return amg_on ? (env ? env : kChunkAmg) : kChunk;
+    }
     void launch_cg_update(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
         hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[slot], nbC,

@@ -71,6 +71,10 @@ typedef struct tsgo_config {
                                 (lambda from 1e-3, x1.1 when chi^2 rose, /1.1 otherwise, within [1e-6, 10]; the `lambdaVal` the C++
                                 declares and never uses, OptimizerCpu.h:70), step `lr`, b zeroed at fixed vertices, stop on ||lr dx|| < 1e-3 only. */
     double lr;               /* rules = 1: the step scale `lr` of GraphOptimizer.optimize(iterations, lr) (slam_main.py passes 0.2); ignored by rules = 0 */
+    int32_t odom_jacobian;   /* 0 (default): the reference's ODOM Jacobians, the constants A = -I, B = +I (remote/graph/edge/EdgeSe2.h:35-37;
+                                parity).  1: the analytic Jacobians of the same residual under the reference's vertex update (SURVEY 8f
+                                rank 4; README.md:53 "further development") — same fixed points, and pose graphs with loop closures, which
+                                diverge under the constants ("Error is getting worse"), converge. */
     int32_t reuse_structure; /* 1 (default): tsgo_set_graph with the SAME vertex ids/types, edge list and fixed list as the graph the
                                 handle already holds only refills estimates, measurements and weights (the reference re-creates
                                 everything per message, remote/app/ConnectionHandler.h:18-21); 0: always rebuild.  Same results. */

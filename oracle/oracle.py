@@ -40,6 +40,12 @@ def set_threads(n):
     lib().oracle_set_threads(int(n))
 
 
+def set_odom_jacobian(kind):
+    """"constant" (the reference: A = -I, B = +I, EdgeSe2.h:35-37) or "analytic" (the extension of SURVEY 8f rank 4).  Process-wide:
+    every oracle entry point, dense and twin, follows it.  Tests that switch it switch it back."""
+    lib().oracle_set_odom_jacobian({"constant": 0, "analytic": 1}[kind])
+
+
 def lib():
     global _LIB
     if _LIB is None:

@@ -29,6 +29,8 @@
 #include "host/problem.h"
 #include "tsgo_math.h"
 
+extern "C" int oracle_get_odom_jacobian(void);      // oracle_dense.cpp: 0 = the reference's constants, 1 = analytic (extension)
+
 namespace {
 
 using tsgo::kNoEdge; using tsgo::kWave; using tsgo::kDirBit;
@@ -47,6 +49,7 @@ struct Twin {
     double chi2 = 0;
     std::vector<double> gscratch;
     bool use_amg = false;
+    bool analytic = false;                          // analytic ODOM Jacobians (extension; tsgo_math.h: odom_blocks)
     double lambda = 0; bool zero_fixed = false;     // the Python optimizer's rules (graph_optimizer.py:42,150), as Engine::launch_lin; 0 / false: cpu eigen
     double step = tsgo::kStepScale;
     int n_lin = 0;
@@ -68,7 +71,9 @@ struct Twin {
             ps[4 * (size_t)i] = pr.pose_xyt[3 * (size_t)i]; ps[4 * (size_t)i + 1] = pr.pose_xyt[3 * (size_t)i + 1];
             ps[4 * (size_t)i + 2] = std::cos(th[i]); ps[4 * (size_t)i + 3] = std::sin(th[i]);
         }
-        pa.assign(4 * pr.by_pose.slots(), 0); la.assign(4 * pr.by_lm.slots(), 0); oa.assign(3 * pr.odom.slots(), 0);
+        analytic = oracle_get_odom_jacobian() != 0;
+        pr.odom_analytic = analytic;
+        pa.assign(4 * pr.by_pose.slots(), 0); la.assign(4 * pr.by_lm.slots(), 0); oa.assign((analytic ? 6 : 3) * pr.odom.slots(), 0);
         dlinv.assign((size_t)L * 3, 0); u.assign((size_t)L * 2, 0); t.assign((size_t)L * 2, 0);
         part.assign((size_t)P * 18 + 1, 0);
         dp.assign((size_t)P * 6, 0); minv.assign((size_t)P * 6, 0);
@@ -129,7 +134,11 @@ struct Twin {
                 for (int m = 0; m < 9; ++m) o[m] = -acc[m];
                 for (int q = amg.schur.od_ptr[b]; q < amg.schur.od_ptr[b + 1]; ++q) {
                     const size_t e = amg.schur.od_slot[q];
-                    o[0] -= oa[e]; o[4] -= oa[SO + e]; o[8] -= oa[2 * SO + e];
+                    if (analytic) {
+                        const double k00 = oa[e], k01 = oa[SO + e], k11 = oa[2 * SO + e], g0 = oa[3 * SO + e], g1 = oa[4 * SO + e], w = oa[5 * SO + e];
+                        o[0] -= k00; o[1] -= k01; o[3] -= k01; o[4] -= k11; o[8] -= w;
+                        if (pr.odom.idx[e] & kDirBit) { o[2] += g0; o[5] += g1; } else { o[6] += g0; o[7] += g1; }
+                    } else { o[0] -= oa[e]; o[4] -= oa[SO + e]; o[8] -= oa[2 * SO + e]; }
                 }
             }
         }
@@ -245,10 +254,19 @@ struct Twin {
                 for (int m = 0; m < 6; ++m) mi[m] = od.plane(tsgo::OD_MI0 + m)[k];
                 for (int m = 0; m < 3; ++m) w[m] = od.plane(tsgo::OD_W0 + m)[k];
                 auto o = tsgo::odom_linearize<double>(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], mi, w);
-                for (int m = 0; m < 3; ++m) oa[m * SO + k] = o.a[m];
-                o18[0] += o.a[0]; o18[3] += o.a[1]; o18[5] += o.a[2];
-                const double sg = second ? -1.0 : 1.0;                       // b1 += W e, b2 -= W e
-                for (int m = 0; m < 3; ++m) o18[6 + m] += sg * o.a[m] * o.e[m];
+                if (analytic) {                                              // tsgo_math.h: odom_blocks (as k_lin_pose<.., OJ = 1>)
+                    const auto ob = tsgo::odom_blocks<double>(o, a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], mi);
+                    const double six[6] = {ob.k00, ob.k01, ob.k11, ob.g0, ob.g1, ob.w};
+                    for (int m = 0; m < 6; ++m) oa[m * SO + k] = six[m];
+                    o18[0] += ob.k00; o18[1] += ob.k01; o18[3] += ob.k11;
+                    if (!second) { o18[2] -= ob.g0; o18[4] -= ob.g1; o18[5] += ob.s + ob.w; o18[6] += ob.h0; o18[7] += ob.h1; o18[8] += ob.kt - ob.ht; }
+                    else { o18[5] += ob.w; o18[6] -= ob.h0; o18[7] -= ob.h1; o18[8] -= ob.kt; }
+                } else {
+                    for (int m = 0; m < 3; ++m) oa[m * SO + k] = o.a[m];
+                    o18[0] += o.a[0]; o18[3] += o.a[1]; o18[5] += o.a[2];
+                    const double sg = second ? -1.0 : 1.0;                       // b1 += W e, b2 -= W e
+                    for (int m = 0; m < 3; ++m) o18[6 + m] += sg * o.a[m] * o.e[m];
+                }
                 if (!second) chi += o.rho;
             });
             if (zero_fixed && pr.gauge_p[i] > 0) { o18[6] = 0; o18[7] = 0; o18[8] = 0; }
@@ -321,7 +339,12 @@ struct Twin {
                 o0 += d0; o1 += d1; o2 += d2;
                 for_slots(od, i, [&](size_t k) {
                     const uint32_t j = od.idx[k] & ~kDirBit;
-                    o0 -= oa[k] * v[3 * (size_t)j]; o1 -= oa[SO + k] * v[3 * (size_t)j + 1]; o2 -= oa[2 * SO + k] * v[3 * (size_t)j + 2];
+                    const double* vj = &v[3 * (size_t)j];
+                    if (analytic) {
+                        const double k00 = oa[k], k01 = oa[SO + k], k11 = oa[2 * SO + k], g0 = oa[3 * SO + k], g1 = oa[4 * SO + k], w = oa[5 * SO + k];
+                        o0 -= k00 * vj[0] + k01 * vj[1]; o1 -= k01 * vj[0] + k11 * vj[1]; o2 -= w * vj[2];
+                        if (od.idx[k] & kDirBit) { o0 += g0 * vj[2]; o1 += g1 * vj[2]; } else o2 += g0 * vj[0] + g1 * vj[1];
+                    } else { o0 -= oa[k] * vj[0]; o1 -= oa[SO + k] * vj[1]; o2 -= oa[2 * SO + k] * vj[2]; }
                 });
             }
             out[3 * (size_t)i] = o0; out[3 * (size_t)i + 1] = o1; out[3 * (size_t)i + 2] = o2;

@@ -1,0 +1,102 @@
+"""tsgo_config.odom_jacobian = 1 on the device (`-m gpu`): against the dense restatement with the same analytic Jacobians
+(which tests/test_analytic_odometry.py pins by finite differences), against the twin at a size the dense path cannot hold,
+through the collective path, through a structure refill, and under the Python rules."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import edge_cases, independent, util
+from toyslam_amd import synth
+from toyslam_amd.optimizer import HipOptimizer
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture
+def analytic():
+    oracle.set_odom_jacobian("analytic")
+    yield
+    oracle.set_odom_jacobian("constant")
+
+
+@pytest.mark.parametrize("precond", ["amg", "jacobi"])
+def test_device_with_analytic_jacobians_matches_the_dense_restatement(analytic, precond):
+    nonrigid = synth.make(150, 5, loop_closures=6, seed=8)
+    od = np.where(nonrigid.e_type == 0)[0]
+    nonrigid.e_meas[od[3]] = nonrigid.e_meas[od[3]] * np.array([1.05, 1, 1, 1, 0.95, 1, 1, 1, 1])
+    for g, n in ((util.c1_arrays(), 8), (edge_cases.pose_graph_without_landmarks(), 12), (nonrigid, 6)):
+        ref = oracle.optimize(util.to_oracle(g), n, mode="cpp", solver="chol")
+        d_ref, err, diag_ref, grad_ref = util.dense_solution(g)
+        o = HipOptimizer(pcg_rel_tol=1e-12, preconditioner=precond, odom_jacobian="analytic")
+        try:
+            o.set_graph(g)
+            diag, grad, chi2 = o.linearize()
+            step = o.solve_step()
+            r = o.optimize(n); v = o.vertices()
+        finally:
+            o.close()
+        assert abs(chi2 - err) <= 1e-12 * err
+        np.testing.assert_allclose(grad, grad_ref, rtol=0, atol=1e-10 * np.abs(grad_ref).max())
+        np.testing.assert_allclose(diag, diag_ref, rtol=0, atol=1e-10 * np.abs(diag_ref).max())     # the ODOM diagonal blocks are full 3x3 now
+        assert np.abs(step["delta"] - d_ref).max() <= 1e-8 * np.abs(d_ref).max()
+        assert (r["iters"], r["stop"]) == (ref["iters"], ref["stop"])
+        np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
+        assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-8
+
+
+def test_pose_graph_that_diverges_under_the_reference_jacobians_converges_on_the_device():
+    g = synth.make(3000, 0, loop_closures=60, seed=3)              # odometry + loop closures only
+    o = HipOptimizer(pcg_rel_tol=1e-10)
+    try:
+        o.set_graph(g); r0 = o.optimize(30)
+    finally:
+        o.close()
+    assert r0["stop"] == "worse"                                    # the reference's behaviour, reproduced (OptimizerCpu.h:140-153)
+    o = HipOptimizer(pcg_rel_tol=1e-10, odom_jacobian="analytic")
+    try:
+        o.set_graph(g); r = o.optimize(30); v = o.vertices()
+    finally:
+        o.close()
+    assert r["stop"] == "cap" and np.all(np.diff(r["chi2"]) < 0) and r["chi2"][-1] < 0.01 * r["chi2"][0], r["chi2"]
+    oracle.set_odom_jacobian("analytic")
+    try:
+        ref = oracle.sparse_optimize(util.to_oracle(g), 30, pcg_tol=1e-12, precond="jacobi")
+        gf = g.copy(); gf.v_pos[:] = v
+        chi_np = independent.Linearisation(gf).chi2                 # the numpy checker, on the device's final state
+    finally:
+        oracle.set_odom_jacobian("constant")
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-7)
+    assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-6
+    assert chi_np < r["chi2"][-1]
+
+
+def test_analytic_jacobians_at_config_2_collective_path_refill_and_python_rules(analytic):
+    g = synth.make(10000, 10, loop_closures=200, seed=4)
+    ref = oracle.sparse_optimize(util.to_oracle(g), 5, pcg_tol=1e-12, precond="jacobi")
+    lin = independent.Linearisation(g)
+    o = HipOptimizer(pcg_rel_tol=1e-12, odom_jacobian="analytic", rank=0, world=1)
+    try:
+        o.comm_init(o.comm_unique_id())                             # the sharded code path (eager launches, all-reduced level-0 blocks)
+        o.set_graph(g)
+        diag, grad, chi2 = o.linearize()
+        step = o.solve_step()
+        r = o.optimize(5); v = o.vertices()
+        assert abs(chi2 - lin.chi2) <= 1e-11 * lin.chi2
+        np.testing.assert_allclose(grad, lin.gradient(), rtol=0, atol=1e-9 * np.abs(grad).max())
+        np.testing.assert_allclose(diag, lin.diag_blocks(), rtol=0, atol=1e-9 * np.abs(diag).max())
+        assert lin.residual_of(step["delta"]) < 1e-9                # H delta = b with the full ODOM blocks, checked matrix-free in numpy
+        np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
+        assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-7
+        assert r["cg_iters"].max() < 80 and r["fallbacks"] == 0
+        o.set_graph(g); r2 = o.optimize(5)                          # same structure: refilled, same answer
+        assert r2["structure_reused"]
+        np.testing.assert_array_equal(r2["chi2"], r["chi2"])
+    finally:
+        o.close()
+    refp = oracle.sparse_optimize(util.to_oracle(g), 4, pcg_tol=1e-12, precond="amg", rules="python", lr=0.7)
+    o = HipOptimizer(pcg_rel_tol=1e-12, odom_jacobian="analytic", rules="python", lr=0.7)
+    try:
+        o.set_graph(g); rp = o.optimize(4)
+    finally:
+        o.close()
+    np.testing.assert_allclose(rp["chi2"], refp["chi2"], rtol=1e-9)

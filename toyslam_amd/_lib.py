@@ -12,7 +12,7 @@ class tsgo_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("pcg_rel_tol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("lanes_per_pose", C.c_int32), ("lanes_per_lm", C.c_int32),
                 ("use_graphs", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("verbose", C.c_int32),
-                ("preconditioner", C.c_int32), ("xcd_map", C.c_int32), ("warm_start", C.c_int32), ("rules", C.c_int32), ("lr", C.c_double), ("reuse_structure", C.c_int32)]
+                ("preconditioner", C.c_int32), ("xcd_map", C.c_int32), ("warm_start", C.c_int32), ("rules", C.c_int32), ("lr", C.c_double), ("odom_jacobian", C.c_int32), ("reuse_structure", C.c_int32)]
 
 
 class tsgo_stats(C.Structure):

@@ -452,6 +452,7 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
     for (int i = 0; i < P; ++i) { xy[2 * (size_t)i] = pr.pose_xyt[3 * (size_t)i]; xy[2 * (size_t)i + 1] = pr.pose_xyt[3 * (size_t)i + 1]; }
     std::vector<char> rigid(P, 0);
     for (int i = 0; i < P; ++i) for_slots(pr.by_pose, i, [&](size_t) { rigid[i] = 1; });
+    if (pr.odom_analytic) for (int i = 0; i < P; ++i) for_slots(pr.odom, i, [&](size_t) { rigid[i] = 1; });   // A = [[-M, q], ..]: q is the lever arm
     L0.agg.resize(P);
     // aggregate size per level; research override: TSGO_AGG_LIST="8,4,4,8" (last entry repeats) or TSGO_AGG0 / TSGO_AGGC
     std::vector<int> agg_list;
@@ -516,6 +517,7 @@ std::string build_amg_sharded(const tsgo_graph& g, const Problem& local, AmgSym&
     BuildOptions bo; bo.lanes_per_pose = local.by_pose.G; bo.lanes_per_lm = local.by_lm.G;
     std::string err = build_problem(g, bo, full);
     if (!err.empty()) return err;
+    full.odom_analytic = local.odom_analytic;
     if (full.P != local.P || full.pose_vertex != local.pose_vertex) return "shard and whole-graph pose numbering differ";
     AmgSym S;
     err = build_amg(full, S);

@@ -63,6 +63,8 @@ struct Problem {
     std::vector<double> gauge_p, gauge_l;   // 1e6 * multiplicity in the fixed list: every pose (applied by the shard that owns it), owned landmarks
     SellTable by_pose, by_lm, odom;
     int n_vertices = 0;                 // of the input graph
+    bool odom_analytic = false;         // analytic ODOM Jacobians (tsgo_config.odom_jacobian): odometry then couples heading to translation,
+                                        // so every pose an edge touches carries a lever arm in the multigrid coarse space (host/amg.cpp)
 };
 
 struct BuildOptions {

@@ -56,7 +56,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
                                                          const uint32_t* __restrict__ slot_k, const int* __restrict__ optr,
                                                          const uint32_t* __restrict__ oslot, Table<T> tb, const T* __restrict__ od_dyn,
                                                          size_t od_slots, const T* __restrict__ lmrec, const T* __restrict__ ps,
-                                                         const T* __restrict__ part, HT<T>* __restrict__ A, int diag_on) {
+                                                         const T* __restrict__ part, HT<T>* __restrict__ A, int diag_on,
+                                                         const uint32_t* __restrict__ od_idx, int odom_analytic) {
     const int b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= nnz) return;
     const int i = blk_row[b], k = blk_col[b];
@@ -95,13 +96,17 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
         acc[6] -= vq0 * ck - vq1 * sk; acc[7] -= vq0 * sk + vq1 * ck;
         acc[8] += vi0 * qv0 + vi1 * qv1;
     }
-    T d0 = 0, d1 = 0, d2 = 0;
+    T d[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // the odometry edges joining i and k: -diag(a) each, or the full H_12 / H_21 of the analytic Jacobians
     for (int q = optr[b]; q < optr[b + 1]; ++q) {
         const size_t e = oslot[q];
-        d0 += od_dyn[e]; d1 += od_dyn[od_slots + e]; d2 += od_dyn[2 * od_slots + e];
+        if (odom_analytic) {
+            const T k00 = od_dyn[e], k01 = od_dyn[od_slots + e], k11 = od_dyn[2 * od_slots + e], g0 = od_dyn[3 * od_slots + e], g1 = od_dyn[4 * od_slots + e], w = od_dyn[5 * od_slots + e];
+            d[0] -= k00; d[1] -= k01; d[3] -= k01; d[4] -= k11; d[8] -= w;
+            if (od_idx[e] & kDirMask) { d[2] += g0; d[5] += g1; } else { d[6] += g0; d[7] += g1; }      // row pose = second / first endpoint
+        } else { d[0] -= od_dyn[e]; d[4] -= od_dyn[od_slots + e]; d[8] -= od_dyn[2 * od_slots + e]; }
     }
-    o[0] = -acc[0] - d0; o[1] = -acc[1]; o[2] = -acc[2]; o[3] = -acc[3]; o[4] = -acc[4] - d1; o[5] = -acc[5];
-    o[6] = -acc[6]; o[7] = -acc[7]; o[8] = -acc[8] - d2;
+#pragma unroll
+    for (int m = 0; m < 9; ++m) o[m] = -acc[m] + d[m];
 }
 
 template <typename T>

@@ -515,6 +515,7 @@ template <typename T> struct Engine : IEngine {
         bo.fill_planes = false;
         const std::string err = build_problem(g, bo, pr);
         if (!err.empty()) return set_error(-2, "tsgo_set_graph: " + err);
+        pr.odom_analytic = oj();
         const bool say = cfg.verbose || getenv("TSGO_VERBOSE");
         auto lap = [&, last = t0](const char* what) mutable {
             const auto n = std::chrono::steady_clock::now();
@@ -534,7 +535,7 @@ template <typename T> struct Engine : IEngine {
         if (int rc = upload_T(&gauge_l, pr.gauge_l.data(), pr.gauge_l.size())) return rc;
         if (int rc = alloc_table(tp, &st_p, pr.by_pose, 4, 4, true)) return rc;
         if (int rc = alloc_table(tl, &st_l, pr.by_lm, 4, 4, true)) return rc;
-        if (int rc = alloc_table(to, &st_o, pr.odom, 9, 3, false)) return rc;
+        if (int rc = alloc_table(to, &st_o, pr.odom, 9, oj() ? 6 : 3, false)) return rc;
         if (int rc = stage_values(g)) return rc;
         // table-kernel grids are multiples of 8 (one eighth of the slices per XCD, see xcd_block())
         nbP = 8 * (((tp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);
@@ -586,11 +587,18 @@ template <typename T> struct Engine : IEngine {
     // damping of the current linearisation (rules = 1, graph_optimizer.py:24-43; 0 under the cpu/eigen rules) and the step the update takes
     double lambda = 0;
     bool py_rules() const { return cfg.rules == 1; }
+    bool oj() const { return cfg.odom_jacobian == 1; }      // analytic ODOM Jacobians (tsgo_math.h: odom_blocks)
     double step_scale() const { return py_rules() ? cfg.lr : kStepScale; }
     void launch_lin() {
         const int zf = py_rules() ? 1 : 0;
         if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv, (T)lambda, zf);
-        LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
+        if (oj()) LAUNCH_GM(pr.by_pose.G, k_lin_pose, 1, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
+        else LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
+    }
+    void launch_lin_pose_only() {       // tsgo_time_kernel
+        const int zf = py_rules() ? 1 : 0;
+        if (oj()) LAUNCH_GM(pr.by_pose.G, k_lin_pose, 1, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
+        else LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
     }
     void launch_finalize() {
         hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0], (const T*)(amg_on ? omega_dev : one_dev), gscale_dev);
@@ -603,12 +611,16 @@ template <typename T> struct Engine : IEngine {
     int launch_matvec(int slot, bool with_rz = false, bool low = false) {
         if (low) {
             if (tl.n_slices > 0) LAUNCH_GML(pr.by_lm.G, k_schur_lm, 0, 1, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
-            LAUNCH_GML1(pr.by_pose.G, k_schur_pose, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
-                        (const T*)nullptr, rzpart);
+            if (oj()) LAUNCH_GML(pr.by_pose.G, k_schur_pose, 1, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
+                                 (const T*)nullptr, rzpart);
+            else LAUNCH_GML1(pr.by_pose.G, k_schur_pose, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
+                             (const T*)nullptr, rzpart);
         } else {
             if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
-            LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
-                     (const T*)(with_rz ? r : nullptr), rzpart);
+            if (oj()) LAUNCH_GML(pr.by_pose.G, k_schur_pose, 0, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
+                                 (const T*)(with_rz ? r : nullptr), rzpart);
+            else LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
+                          (const T*)(with_rz ? r : nullptr), rzpart);
         }
         return allreduce(sbuf, (size_t)pr.P * 3 + nbP);
     }
@@ -621,7 +633,8 @@ template <typename T> struct Engine : IEngine {
         // all-reduced linearisation partials, identical everywhere) is contributed by rank 0 alone; one all-reduce
         // makes level 0 whole and identical on every rank, everything below it is then computed redundantly
         hipLaunchKernelGGL((k_schur_blocks<T>), dim3(grid_for(L0.nnzA)), dim3(kBlock), 0, stream, L0.nnzA, L0.A_row, L0.A_col, sc_ptr, sc_si, sc_sk,
-                           sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A, pr.rank == 0 ? 1 : 0);
+                           sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A, pr.rank == 0 ? 1 : 0,
+                           to.idx, oj() ? 1 : 0);
         if (int rc = allreduce_h(L0.A, (size_t)L0.nnzA * 9)) return rc;
         for (size_t l = 0; l < lv.size(); ++l) {
             DevLevel<T>& L = lv[l];
@@ -1180,7 +1193,9 @@ template <typename T> struct Engine : IEngine {
             for (int k = 0; k < n; ++k) {
                 switch (which) {
                     case 0: if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[0], T(0), dl, npart); break;
-                    case 1: LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[0], (const T*)nullptr, (T*)nullptr); break;
+                    case 1: if (oj()) LAUNCH_GML(pr.by_pose.G, k_schur_pose, 0, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[0], (const T*)nullptr, (T*)nullptr);
+                            else LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[0], (const T*)nullptr, (T*)nullptr);
+                            break;
                     case 2: {   // state slot 1 is never written here, slot 0 stays "iters = 0, not done"
                         const T tol2 = (T)0;
                         hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[0], nbC,
@@ -1188,7 +1203,7 @@ template <typename T> struct Engine : IEngine {
                         break;
                     }
                     case 3: if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv, (T)lambda, py_rules() ? 1 : 0); break;
-                    case 4: LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, py_rules() ? 1 : 0); break;
+                    case 4: launch_lin_pose_only(); break;
                     case 6: if (amg_on) { if (int rc = launch_amg_setup()) return rc; } break;
                     default: if (int rc = launch_iteration(0)) return rc; if (int rc = launch_iteration(1)) return rc; break;
                 }

@@ -153,7 +153,8 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restr
 // K2 lin_pose: per pose — pose-side linearisation of its LM edges + its ODOM rows.
 //   writes: slot planes (pose-major copy), ODOM weights, part[i][18] = Dp(6) g(3) Sd(6) Wu(3) in the
 //           world frame, one chi^2 partial per workgroup
-template <typename T, int G>
+// OJ = 1: analytic ODOM Jacobians (tsgo_math.h: odom_blocks); the ODOM table then carries six dynamic planes (k00 k01 k11 g0 g1 w).
+template <typename T, int G, int OJ = 0>
 __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, const T* __restrict__ ps,
                                                      const T* __restrict__ lmrec, const T* __restrict__ gauge_p,
                                                      int pose_first, int pose_last, T* __restrict__ part,
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
         }
         // ODOM rows (listed at both endpoints; chi^2 counted at id1)
         T od0 = 0, od1 = 0, od2 = 0, og0 = 0, og1 = 0, og2 = 0;
+        T od01 = 0, od02 = 0, od12 = 0;        // off-diagonal entries of the pose's ODOM diagonal block: analytic Jacobians only
         {
             const size_t S = od.slots;
             const uint32_t r0 = od.row_off[slice], r1 = od.row_off[slice + 1];
@@ -219,10 +221,19 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
                 const T xj = oq[0], yj = oq[1], cj = oq[2], sj = oq[3];
                 const OdomLin<T> o = second ? odom_linearize<T>(xj, yj, cj, sj, x0, y0, c, s, mi, w)
                                             : odom_linearize<T>(x0, y0, c, s, xj, yj, cj, sj, mi, w);
-                od.dyn[k] = o.a[0]; od.dyn[S + k] = o.a[1]; od.dyn[2 * S + k] = o.a[2];
-                od0 += o.a[0]; od1 += o.a[1]; od2 += o.a[2];
-                const T sg = second ? T(-1) : T(1);
-                og0 += sg * o.a[0] * o.e[0]; og1 += sg * o.a[1] * o.e[1]; og2 += sg * o.a[2] * o.e[2];
+                if (OJ) {
+                    const OdomBlocks<T> ob = second ? odom_blocks<T>(o, xj, yj, cj, sj, x0, y0, c, s, mi) : odom_blocks<T>(o, x0, y0, c, s, xj, yj, cj, sj, mi);
+                    od.dyn[k] = ob.k00; od.dyn[S + k] = ob.k01; od.dyn[2 * S + k] = ob.k11;
+                    od.dyn[3 * S + k] = ob.g0; od.dyn[4 * S + k] = ob.g1; od.dyn[5 * S + k] = ob.w;
+                    od0 += ob.k00; od01 += ob.k01; od1 += ob.k11;
+                    if (!second) { od02 -= ob.g0; od12 -= ob.g1; od2 += ob.s + ob.w; og0 += ob.h0; og1 += ob.h1; og2 += ob.kt - ob.ht; }
+                    else { od2 += ob.w; og0 -= ob.h0; og1 -= ob.h1; og2 -= ob.kt; }
+                } else {
+                    od.dyn[k] = o.a[0]; od.dyn[S + k] = o.a[1]; od.dyn[2 * S + k] = o.a[2];
+                    od0 += o.a[0]; od1 += o.a[1]; od2 += o.a[2];
+                    const T sg = second ? T(-1) : T(1);
+                    og0 += sg * o.a[0] * o.e[0]; og1 += sg * o.a[1] * o.e[1]; og2 += sg * o.a[2] * o.e[2];
+                }
                 // a padding slot has w = 0: rho = 0 there
                 if (!second) chi += o.rho;
             }
@@ -231,6 +242,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
         GS(sA0); GS(sA1); GS(sAv0); GS(sAv1); GS(sVV); GS(ge0); GS(ge1); GS(get);
         GS(K00); GS(K01); GS(K11); GS(Kv0); GS(Kv1); GS(vKv); GS(wu0); GS(wu1); GS(wut);
         GS(od0); GS(od1); GS(od2); GS(og0); GS(og1); GS(og2);
+        if (OJ) { GS(od01); GS(od02); GS(od12); }
 #undef GS
         if (valid && (lane % G) == 0) {
             // gauge and damping enter once: through the shard that owns the pose
@@ -238,8 +250,8 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
             const T ga = own ? gauge_p[i] + lambda : T(0);
             const bool fixed_here = zero_fixed && gauge_p[i] > T(0);      // gauge_p holds the owned poses' terms; others see 0 and the owner's partial decides
             T* o = part + (size_t)i * 18;
-            o[0] = c * c * sA0 + s * s * sA1 + od0 + ga; o[1] = c * s * (sA0 - sA1); o[3] = s * s * sA0 + c * c * sA1 + od1 + ga;
-            o[2] = -(c * sAv0 - s * sAv1); o[4] = -(s * sAv0 + c * sAv1); o[5] = sVV + od2 + ga;
+            o[0] = c * c * sA0 + s * s * sA1 + od0 + ga; o[1] = c * s * (sA0 - sA1) + od01; o[3] = s * s * sA0 + c * c * sA1 + od1 + ga;
+            o[2] = -(c * sAv0 - s * sAv1) + od02; o[4] = -(s * sAv0 + c * sAv1) + od12; o[5] = sVV + od2 + ga;
             o[6] = c * ge0 - s * ge1 + og0; o[7] = s * ge0 + c * ge1 + og1; o[8] = -get + og2;
             if (fixed_here) { o[6] = 0; o[7] = 0; o[8] = 0; }
             o[9] = c * c * K00 - 2 * c * s * K01 + s * s * K11;
@@ -374,7 +386,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
 // ------------------------------------------------------------------------------------------------
 // KB schur_pose: per pose — out = Hpp v - W t (this shard's share), partial dot (out, v).
 // HOT KERNEL 2 of the PCG iteration.
-template <typename T, int G, int LOW = 0>
+template <typename T, int G, int LOW = 0, int OJ = 0>
 __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od, const T* __restrict__ zc,
                                                        const T* __restrict__ t, const T* __restrict__ dp,
                                                        int pose_first, int pose_last, T* __restrict__ out,
@@ -428,9 +440,15 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
             const uint32_t r0 = od.row_off[slice], r1 = od.row_off[slice + 1];
             for (uint32_t row = r0; row < r1; ++row) {
                 const size_t k = (size_t)row * 64 + lane;
-                const uint32_t j = od.idx[k] & ~kDirMask;
+                const uint32_t raw = od.idx[k];
+                const uint32_t j = raw & ~kDirMask;
                 const T* zj = zc + (size_t)j * kPoseRec;
-                o0 -= od.dyn[k] * zj[0]; o1 -= od.dyn[S + k] * zj[1]; o2 -= od.dyn[2 * S + k] * zj[2];
+                if (OJ) {           // H_12 = [[-K, 0], [g^T, -w]] seen from the first endpoint, its transpose from the second
+                    const T k00 = od.dyn[k], k01 = od.dyn[S + k], k11 = od.dyn[2 * S + k], g0 = od.dyn[3 * S + k], g1 = od.dyn[4 * S + k], w = od.dyn[5 * S + k];
+                    const T zt0 = zj[0], zt1 = zj[1], zth = zj[2];
+                    o0 -= k00 * zt0 + k01 * zt1; o1 -= k01 * zt0 + k11 * zt1; o2 -= w * zth;
+                    if (raw & kDirMask) { o0 += g0 * zth; o1 += g1 * zth; } else o2 += g0 * zt0 + g1 * zt1;
+                } else { o0 -= od.dyn[k] * zj[0]; o1 -= od.dyn[S + k] * zj[1]; o2 -= od.dyn[2 * S + k] * zj[2]; }
             }
         }
         acc0 = group_sum<T, G>(acc0); acc1 = group_sum<T, G>(acc1); acc2 = group_sum<T, G>(acc2);

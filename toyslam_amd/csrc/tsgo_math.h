@@ -57,6 +57,37 @@ TSGO_HD LmLin<T> lm_linearize(T x, T y, T c, T s, T lx, T ly, T zx, T zy, T w0, 
 // ODOM edge: pose1 (x1,y1,c1,s1) -> pose2; mi = top two rows of meas^-1 (row-major 2x3).
 template <typename T> struct OdomLin { T a[3], e[3], rho; };
 
+// Analytic Jacobians of that residual (tsgo_config.odom_jacobian = 1; an extension: the reference's are the constants
+// A = -I, B = +I, EdgeSe2.h:35-37) under the reference's own vertex update (theta and the world-frame translation are
+// added to, VertexSe2.h:16-27).  With N = the 2x2 corner of meas^-1 and M = N R1^T:
+//   A = [[-M, q], [0 0 -kappa]],  B = [[M, 0], [0 0 kappa]],  q = N (dR1^T/dth1)(t2 - t1) = N (py, -px),  kappa = d e_th / d(th2 - th1).
+// What the passes need of the edge's blocks (Omega_t = diag(a0, a1) Huber-scaled):
+//   K = M^T Omega_t M (k00 k01 k11),  g = M^T Omega_t q,  s = q^T Omega_t q,  w = a2 kappa^2
+//   H_11 += [[K, -g], [., s + w]],  H_22 += [[K, 0], [0, w]],  H_12 = [[-K, 0], [g^T, -w]]
+//   b_1 = [h; -ht + kt],  b_2 = [-h; -kt]   with h = M^T Omega_t e_t, ht = q^T Omega_t e_t, kt = kappa a2 e_th
+// (M = I, q = 0, kappa = 1 gives back the constant-Jacobian blocks: K = diag(a0, a1), w = a2, b = +-a e.)
+template <typename T> struct OdomBlocks { T k00, k01, k11, g0, g1, s, w, h0, h1, ht, kt; };
+
+template <typename T>
+TSGO_HD OdomBlocks<T> odom_blocks(const OdomLin<T>& o, T x1, T y1, T c1, T s1, T x2, T y2, T c2, T s2, const T* mi) {
+    OdomBlocks<T> b;
+    const T dx = x2 - x1, dy = y2 - y1;
+    const T px = c1 * dx + s1 * dy, py = c1 * dy - s1 * dx;
+    const T m00 = mi[0] * c1 - mi[1] * s1, m01 = mi[0] * s1 + mi[1] * c1, m10 = mi[3] * c1 - mi[4] * s1, m11 = mi[3] * s1 + mi[4] * c1;
+    const T q0 = mi[0] * py - mi[1] * px, q1 = mi[3] * py - mi[4] * px;
+    const T cc = c1 * c2 + s1 * s2, ss = c1 * s2 - s1 * c2;
+    const T d00 = mi[0] * cc + mi[1] * ss, d10 = mi[3] * cc + mi[4] * ss;
+    const T e00 = -mi[0] * ss + mi[1] * cc, e10 = -mi[3] * ss + mi[4] * cc;
+    const T kappa = (d00 * e10 - d10 * e00) / (d00 * d00 + d10 * d10);
+    const T a0 = o.a[0], a1 = o.a[1], a2 = o.a[2];
+    b.k00 = m00 * m00 * a0 + m10 * m10 * a1; b.k01 = m00 * m01 * a0 + m10 * m11 * a1; b.k11 = m01 * m01 * a0 + m11 * m11 * a1;
+    b.g0 = m00 * a0 * q0 + m10 * a1 * q1; b.g1 = m01 * a0 * q0 + m11 * a1 * q1;
+    b.s = a0 * q0 * q0 + a1 * q1 * q1; b.w = a2 * kappa * kappa;
+    b.h0 = m00 * a0 * o.e[0] + m10 * a1 * o.e[1]; b.h1 = m01 * a0 * o.e[0] + m11 * a1 * o.e[1];
+    b.ht = a0 * q0 * o.e[0] + a1 * q1 * o.e[1]; b.kt = kappa * a2 * o.e[2];
+    return b;
+}
+
 template <typename T>
 TSGO_HD OdomLin<T> odom_linearize(T x1, T y1, T c1, T s1, T x2, T y2, T c2, T s2, const T* mi, const T* w) {
     OdomLin<T> o;

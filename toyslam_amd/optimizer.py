@@ -17,7 +17,7 @@ STOP = {0: "cap", 1: "worse", 2: "plateau", 3: "converged", 4: "solver_failed"}
 class HipOptimizer:
     def __init__(self, device=0, precision=64, pcg_rel_tol=1e-10, pcg_max_iters=20000, lanes_per_pose=0,
                  lanes_per_lm=0, use_graphs=True, rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None,
-                 reuse_structure=None, rules="cpp", lr=0.2):
+                 reuse_structure=None, rules="cpp", lr=0.2, odom_jacobian="constant"):
         self.lib = _lib.hip_lib()
         cfg = _lib.tsgo_config()
         self.lib.tsgo_default_config(C.byref(cfg))
@@ -32,6 +32,7 @@ class HipOptimizer:
         if reuse_structure is not None:
             cfg.reuse_structure = int(reuse_structure)
         cfg.rules, cfg.lr = {"cpp": 0, "python": 1}[rules], float(lr)
+        cfg.odom_jacobian = {"constant": 0, "analytic": 1}[odom_jacobian]
         self.cfg = cfg
         self.h = C.c_void_p()
         _lib.check(self.lib, self.lib.tsgo_create(C.byref(cfg), C.byref(self.h)), "tsgo_create")

@@ -80,6 +80,7 @@ def test_analytic_jacobians_at_config_2_collective_path_refill_and_python_rules(
         o.set_graph(g)
         diag, grad, chi2 = o.linearize()
         step = o.solve_step()
+        o.set_graph(g)                                              # (the probes above left solver history behind: start clean)
         r = o.optimize(5); v = o.vertices()
         assert abs(chi2 - lin.chi2) <= 1e-11 * lin.chi2
         np.testing.assert_allclose(grad, lin.gradient(), rtol=0, atol=1e-9 * np.abs(grad).max())

@@ -78,7 +78,8 @@ TSGO_HD OdomBlocks<T> odom_blocks(const OdomLin<T>& o, T x1, T y1, T c1, T s1, T
     const T cc = c1 * c2 + s1 * s2, ss = c1 * s2 - s1 * c2;
     const T d00 = mi[0] * cc + mi[1] * ss, d10 = mi[3] * cc + mi[4] * ss;
     const T e00 = -mi[0] * ss + mi[1] * cc, e10 = -mi[3] * ss + mi[4] * cc;
-    const T kappa = (d00 * e10 - d10 * e00) / (d00 * d00 + d10 * d10);
+    const T den = d00 * d00 + d10 * d10;
+    const T kappa = den > T(0) ? (d00 * e10 - d10 * e00) / den : T(0);      // a padding slot of the device table has mi = 0 (and zero weights)
     const T a0 = o.a[0], a1 = o.a[1], a2 = o.a[2];
     b.k00 = m00 * m00 * a0 + m10 * m10 * a1; b.k01 = m00 * m01 * a0 + m10 * m11 * a1; b.k11 = m01 * m01 * a0 + m11 * m11 * a1;
     b.g0 = m00 * a0 * q0 + m10 * a1 * q1; b.g1 = m01 * a0 * q0 + m11 * a1 * q1;

@@ -1,5 +1,7 @@
 """Research soak (GPU): random mid-size graphs, 12 GN iterations under the reference's stop rules, HIP path against
-the CPU twin (tight tolerances on both).  Exercises warm start, lagged hierarchy, matched aggregates on many shapes."""
+the CPU twin (tight tolerances on both).  Exercises warm start, lagged hierarchy, matched aggregates on many shapes;
+round 2: every 4th graph with the analytic ODOM Jacobians, every 5th under the Python optimizer's rules (lambda * I, random
+lr), every 3rd sent again to the same handle (structure reuse: bit-identical answer)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -25,21 +27,35 @@ while time.time() < t_end:
         shape = "pose graph"
     fx = [0] + [int(v) for v in rng.choice(g.v_id, size=int(rng.integers(0, 3)), replace=False)]
     g.fixed = np.array(fx, np.uint32)
-    o = HipOptimizer(pcg_rel_tol=1e-11)
+    oj = "analytic" if trial % 4 == 1 else "constant"
+    rules, lr = ("python", float(rng.choice([0.2, 0.5, 1.0]))) if trial % 5 == 2 else ("cpp", 0.2)
+    shape += {"analytic": "+aJ", "constant": ""}[oj] + ("+py%.1f" % lr if rules == "python" else "")
+    o = HipOptimizer(pcg_rel_tol=1e-11, odom_jacobian=oj, rules=rules, lr=lr)
     try:
         o.set_graph(g); r = o.optimize(12); v = o.vertices()
+        if trial % 3 == 0:
+            o.set_graph(g); r2 = o.optimize(12)
+            if not (r2["structure_reused"] and np.array_equal(r2["chi2"], r["chi2"]) and np.array_equal(r2["cg_iters"], r["cg_iters"])):
+                print("trial %d: the refilled handle did not reproduce the first run" % trial); sys.exit(1)
     finally:
         o.close()
-    ref = oracle.sparse_optimize(util.to_oracle(g), 12, pcg_tol=1e-12, precond="amg")
+    oracle.set_odom_jacobian(oj)
+    try:
+        ref = oracle.sparse_optimize(util.to_oracle(g), 12, pcg_tol=1e-12, precond="amg", rules=rules, lr=lr)
+    finally:
+        oracle.set_odom_jacobian("constant")
     d = util.max_vertex_diff(v, ref["v_pos"], g.v_type)
     # the bar is 1e-6 on poses for steps of ordinary size; a diverging run (plain pose graphs with the reference's
     # -I / +I Jacobians take steps of 1e5 and stop on "worse") is compared relative to its step
     bar = 1e-6 * max(1.0, r["delta_norm"] / 1e4)
     diverging = ref["stop"] == "worse"
-    ok = r["iters"] == ref["iters"] and r["stop"] == ref["stop"] and np.allclose(r["chi2"], ref["chi2"], rtol=1e-6 if diverging else 1e-8) \
-        and d < (bar * 10 if diverging else bar)
+    # odometry-only graphs under the analytic Jacobians are beam-like chains (block-Jacobi PCG: > 10^5 iterations at 25k poses,
+    # the multigrid cycle 1 400 - 3 900): two solves to 1e-11 / 1e-12 in the preconditioned norm differ by 1e-5 there
+    beam = shape.startswith("pose graph") and oj == "analytic"
+    ok = r["iters"] == ref["iters"] and r["stop"] == ref["stop"] and np.allclose(r["chi2"], ref["chi2"], rtol=1e-6 if (diverging or beam) else 1e-8) \
+        and d < (bar * 10 if diverging else (1e-4 if beam else bar))
     worst = max(worst, d); most_cg = max(most_cg, int(max(r["cg_iters"]))); fallbacks += int(r["fallbacks"])
-    print("trial %3d %-10s n=%6d k=%2d closures=%4d fixed=%d: GN %d/%d stop %s/%s  cg %s  max vertex diff %.2e  %s"
+    print("trial %3d %-18s n=%6d k=%2d closures=%4d fixed=%d: GN %d/%d stop %s/%s  cg %s  max vertex diff %.2e  %s"
           % (trial, shape, n, k, lc, len(fx), r["iters"], ref["iters"], r["stop"], ref["stop"], list(map(int, r["cg_iters"])), d, "ok" if ok else "MISMATCH"), flush=True)
     if not ok:
         sys.exit(1)

@@ -542,7 +542,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
                                                     CgState<T>* __restrict__ st_out, T* __restrict__ r, T* __restrict__ p,
                                                     T* __restrict__ q, T* __restrict__ x, T* __restrict__ zc,
                                                     const T* __restrict__ minv, const T* __restrict__ omega_ptr, T tol2, int max_iters,
-                                                    const T* __restrict__ gamma0_scale) {
+                                                    const T* __restrict__ gamma0_scale, int stall_iter, T stall_ratio) {
     __shared__ T red[kWavesPerBlock];
     const CgState<T> s = *st_in;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
@@ -558,6 +558,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
         if (writer) *st_out = n;
         return;
     }
+    // stagnation: by stall_iter the multigrid-preconditioned iteration has not reduced r^T M^-1 r below stall_ratio of its start
+    if (s.iters == stall_iter && gamma > stall_ratio * gamma0) { n.done = 1; n.fail = 3; if (writer) *st_out = n; return; }
     T beta, alpha;
     if (s.iters == 0) { beta = 0; alpha = gamma / delta; }
     else { beta = gamma / s.gamma_old; alpha = gamma / (delta - beta * gamma / s.alpha_old); }

@@ -96,14 +96,17 @@ struct IEngine {
 };
 
 constexpr int kRhoSteps = 16, kRhoBlocks = 64, kRhoEvery = 8;   // smoother-damping estimate: power steps, partial sums, refresh period
-constexpr int kAmgIterCap = 400;        // a multigrid-preconditioned solve that needs more than this is treated as a
-                                        // failed preconditioner (stagnation) and repeated with block-Jacobi
+constexpr int kAmgStallIter = 400;      // a multigrid-preconditioned solve that has not even halved r^T M^-1 r by this iteration is treated as a
+constexpr double kAmgStallRatio = 0.5;  // failed preconditioner (stagnation) and repeated with block-Jacobi; one that is converging, however slowly
+                                        // (odometry-only graphs under the analytic Jacobians are beam-like: 600 iterations at 12k poses, where
+                                        // block-Jacobi needs > 10^5), runs on to pcg_max_iters
 constexpr double kMediumPairList = 6;   // Galerkin products whose average pair list is longer than this share an output block among 8 lanes,
 constexpr double kLongPairList = 16;    // ... longer than this among 16 lanes ...
 constexpr double kVeryLongPairList = 200; // ... or a whole wavefront
 constexpr double kCertifySlack = 1e4;   // certificate: sqrt(r^T D^-1 r / b^T D^-1 b) <= slack * tol (norms differ by up to ~sqrt(cond))
 constexpr int kHierMaxAge = 2;          // a multigrid hierarchy serves at most this many consecutive linearisations ...
 constexpr int kHierSlack = 2;           // ... and is rebuilt as soon as a solve needs more than this many iterations over its first
+constexpr int kHierFreshAbove = 64;     // ... and at every linearisation while solves take more iterations than this (a build costs about four)
 constexpr int kChunk = 16;   // PCG iterations per captured hipGraph (even: the state ring has 2 slots)
 constexpr int kChunkAmg = 2; // with the multigrid V-cycle an iteration is ~30 launches and a solve ~50 iterations
 
@@ -805,7 +808,7 @@ template <typename T> struct Engine : IEngine {
     void launch_cg_step(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
         hipLaunchKernelGGL((k_cg_step<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)(sbuf + (size_t)pr.P * 3), (const T*)rzpart, nbP,
-                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, (const T*)omega_dev, tol2, std::min(cfg.pcg_max_iters, kAmgIterCap), (const T*)gscale_dev);
+                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, (const T*)omega_dev, tol2, cfg.pcg_max_iters, (const T*)gscale_dev, kAmgStallIter, (T)kAmgStallRatio);
     }
     // one PCG iteration reading state slot `slot`, writing slot^1
     int launch_iteration(int slot) {
@@ -863,7 +866,7 @@ template <typename T> struct Engine : IEngine {
             // The Galerkin hierarchy is a preconditioner, not the operator: level 0 (the Schur products, its diagonal
             // inverse) is always the current linearisation, the coarse matrices may lag.  They are rebuilt when they
             // have served hier_max_age solves or the last solve took kHierSlack iterations more than the first one did.
-            const bool refresh = hier_age < 0 || hier_age >= hier_max_age || iters_last > iters_fresh + hier_slack;
+            const bool refresh = hier_age < 0 || hier_age >= hier_max_age || iters_last > iters_fresh + hier_slack || iters_last > kHierFreshAbove;
             if (refresh) {
                 if (int rc = launch_amg_setup()) return rc;
                 hier_age = 0;
@@ -883,7 +886,7 @@ template <typename T> struct Engine : IEngine {
 
     // PCG; if the multigrid-preconditioned solve breaks down (indefinite preconditioner), the solve is
     // repeated from the same right-hand side with the block-Jacobi preconditioner.
-    int n_fallbacks = 0;
+    int n_fallbacks = 0, n_hier_retries = 0;
     // Warm start (cfg.warm_start): the Gauss-Newton update takes kStepScale of the solved delta, so (1 - kStepScale) of it
     // is still to go at the next linearisation.  x0 = that remainder, r = b~ - S x0 (one extra product), and the stopping
     // rule keeps measuring against the right-hand side: gamma0 is scaled by (b^T D^-1 b) / (r0^T D^-1 r0).
@@ -901,22 +904,38 @@ template <typename T> struct Engine : IEngine {
         hipLaunchKernelGGL((k_warm_scale<T>), dim3(1), dim3(kBlock), 0, stream, nbC, (const T*)gpart[0], (const T*)npart, amg_on ? (T*)nullptr : gpart[0], gscale_dev);
         return 0;
     }
+    // certify a multigrid-preconditioned solve in a norm the multigrid operator has no part in: r^T D^-1 r against
+    // b^T D^-1 b (partials left by k_pose_finalize in gpart[0]).  An indefinite preconditioner can make r^T M^-1 r small
+    // while r is not.  (k_resid_norm ran and its partials came back with the device state: do_solve_once.)
+    void certify(const int* iters, int* fail) {
+        if (*fail != 0 || !amg_on) return;
+        double num = 0, den = 0;
+        for (int k = 0; k < nbC; ++k) { num += (double)h_scratch[k]; den += (double)h_scratch[nbC + k]; }
+        const double lim = kCertifySlack * cfg.pcg_rel_tol;
+        if (getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] certificate: sqrt(rDr/bDb) = %.3e (tol %.1e, limit %.1e), %d iterations\n", std::sqrt(num / den), cfg.pcg_rel_tol, lim, *iters);
+        if (!(num <= lim * lim * den)) *fail = 1;
+    }
     int do_solve(int* iters, int* fail) {
         if (cfg.warm_start && have_prev) { if (int rc = launch_warm()) return rc; }
         if (int rc = do_solve_once(iters, fail)) return rc;
-        if (*fail == 0 && amg_on) {
-            // certify the multigrid-preconditioned solve in a norm the multigrid operator has no part in:
-            // r^T D^-1 r against b^T D^-1 b (partials left by k_pose_finalize in gpart[0]).  An indefinite
-            // preconditioner can make r^T M^-1 r small while r is not.
-            // (k_resid_norm ran and its partials came back with the device state: do_solve_once)
-            double num = 0, den = 0;
-            for (int k = 0; k < nbC; ++k) { num += (double)h_scratch[k]; den += (double)h_scratch[nbC + k]; }
-            const double lim = kCertifySlack * cfg.pcg_rel_tol;
-            if (getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] certificate: sqrt(rDr/bDb) = %.3e (tol %.1e, limit %.1e), %d iterations\n", std::sqrt(num / den), cfg.pcg_rel_tol, lim, *iters);
-            if (!(num <= lim * lim * den)) *fail = 1;
-        }
-        if (*fail == 2 && amg_on && *iters >= std::min(cfg.pcg_max_iters, kAmgIterCap) && cfg.pcg_max_iters > kAmgIterCap) *fail = 1;
+        certify(iters, fail);
+        if (*fail == 3 && amg_on) *fail = 1;          // stagnation under the multigrid cycle
+        const int age_used = hier_age;
         if (amg_on) { iters_last = *iters; if (hier_age == 0) iters_fresh = *iters; if (hier_age >= 0) ++hier_age; }
+        if (*fail == 1 && amg_on && age_used > 0) {
+            // The hierarchy that failed was built for an earlier linearisation (the lag rule).  Before giving the multigrid
+            // cycle up for this solve, build it for THIS one and solve again from the plain right-hand side: on beam-like
+            // odometry chains (analytic Jacobians) a lagged hierarchy can be indefinite where a fresh one takes 1 400 iterations
+            // and block-Jacobi does not finish in 20 000.
+            ++n_hier_retries;
+            if (int rc = launch_amg_setup()) return rc;
+            hier_age = 0;
+            launch_finalize();
+            if (int rc = do_solve_once(iters, fail)) return rc;
+            certify(iters, fail);
+            if (*fail == 3) *fail = 1;
+            iters_last = *iters; iters_fresh = *iters; hier_age = 1;
+        }
         if (*fail == 1 && amg_on) {
             ++n_fallbacks;
             hier_age = -1;                               // whatever went wrong, start from a fresh hierarchy next time
@@ -961,7 +980,7 @@ template <typename T> struct Engine : IEngine {
             HIP_OK(hipStreamSynchronize(stream));
             if (timing) std::fprintf(stderr, ", drained at %.0f us (iters %d done %d)\n", since(), h_state->iters, h_state->done);
             if (h_state->done) break;
-            if (launched > std::max(cfg.pcg_max_iters, kAmgIterCap) + 2 * ch) return set_error(-20, "PCG did not terminate");
+            if (launched > cfg.pcg_max_iters + 2 * ch) return set_error(-20, "PCG did not terminate");
         }
         *iters = h_state->iters; *fail = h_state->fail;
         predicted_cg = h_state->iters;
@@ -1045,7 +1064,7 @@ template <typename T> struct Engine : IEngine {
             HIP_OK(hipEventRecord(ev[2], stream));
             if (it < TSGO_MAX_TRACE) s.pcg_iters[it] = cg;
             s.pcg_iters_total += cg;
-            if (fail == 1) { s.stop_reason = TSGO_STOP_SOLVER; break; }
+            if (fail != 0) { s.stop_reason = TSGO_STOP_SOLVER; break; }       // breakdown, or pcg_max_iters reached without convergence: no step is taken
             double np2 = 0, nl2 = 0;
             if (int rc = do_backsub_update((T)step, &np2, &nl2)) return rc;   // :159-165 / graph_optimizer.py:66-75
             HIP_OK(hipEventRecord(ev[3], stream));
@@ -1141,7 +1160,7 @@ template <typename T> struct Engine : IEngine {
         std::memset(delta, 0, sizeof(double) * 3 * (size_t)pr.n_vertices);
         for (int i = 0; i < P; ++i) for (int k = 0; k < 3; ++k) delta[3 * (size_t)pr.pose_vertex[i] + k] = hx[(size_t)i * 3 + k];
         for (int l = 0; l < L; ++l) for (int k = 0; k < 2; ++k) delta[3 * (size_t)pr.lm_vertex[l] + k] = hd[(size_t)l * 2 + k];
-        return fail == 1 ? set_error(-21, "PCG breakdown") : 0;
+        return fail == 1 ? set_error(-21, "PCG breakdown") : (fail != 0 ? set_error(-22, "PCG did not converge within pcg_max_iters") : 0);
     }
 
     int cycle_probe(int reps, tsgo_cycle_level* out, int cap) override {

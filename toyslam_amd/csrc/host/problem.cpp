@@ -3,6 +3,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <numeric>
 #include <unordered_map>
 
@@ -54,11 +55,12 @@ int auto_lanes_lm(double mean_degree) {
 bool valid_lanes(int g) { return g == 1 || g == 2 || g == 4 || g == 8; }
 
 // order[i] = class index placed at internal position i; degree-descending inside windows.
-std::vector<int> window_sort(const std::vector<int>& degree) {
+std::vector<int> window_sort(const std::vector<int>& degree, int window) {
     std::vector<int> order(degree.size());
     std::iota(order.begin(), order.end(), 0);
-    for (size_t b = 0; b < order.size(); b += kSortWindow) {
-        const size_t e = std::min(order.size(), b + (size_t)kSortWindow);
+    if (window <= 1) return order;
+    for (size_t b = 0; b < order.size(); b += (size_t)window) {
+        const size_t e = std::min(order.size(), b + (size_t)window);
         std::stable_sort(order.begin() + b, order.begin() + e, [&](int x, int y) { return degree[x] > degree[y]; });
     }
     return order;
@@ -167,11 +169,13 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
 
     // ---- internal numbering --------------------------------------------------------------------------
     // poses: global (identical on every shard) -> sort by the FULL graph's LM degree
-    const std::vector<int> pose_order = window_sort(deg_pose_lm);       // internal -> class
+    static const int win_pose = getenv("TSGO_SORT_WINDOW_POSE") ? atoi(getenv("TSGO_SORT_WINDOW_POSE")) : kSortWindow;     // research
+    static const int win_lm = getenv("TSGO_SORT_WINDOW_LM") ? atoi(getenv("TSGO_SORT_WINDOW_LM")) : kSortWindow;
+    const std::vector<int> pose_order = window_sort(deg_pose_lm, win_pose);       // internal -> class
     std::vector<int> pose_internal(P);
     for (int i = 0; i < P; ++i) pose_internal[pose_order[i]] = i;
     std::vector<int> deg_lm_local(deg_lm.begin() + pr.lm_first, deg_lm.begin() + pr.lm_last);
-    const std::vector<int> lm_order = window_sort(deg_lm_local);        // internal(local) -> class - lm_first
+    const std::vector<int> lm_order = window_sort(deg_lm_local, win_lm);        // internal(local) -> class - lm_first
     std::vector<int> lm_internal(L);
     for (int i = 0; i < L; ++i) lm_internal[lm_order[i]] = i;
 

@@ -98,3 +98,26 @@ def test_c2_fifty_iterations_like_the_config_says():
     gf = g.copy(); gf.v_pos[:] = v
     chi_np = independent.Linearisation(gf).chi2
     assert abs(chi_dev - chi_np) <= 1e-9 * chi_np
+
+
+def test_c3_twelve_iterations_final_chi2_and_poses():
+    """BASELINE config 3 at full size, the bar north_star states: final chi^2 (relative) and pose deltas (absolute) within 1e-6 —
+    twelve Gauss-Newton iterations at the bench's tolerance (1e-10) against the tightly converged twin (1e-12), and the device's
+    final state re-linearised by the numpy checker, which shares nothing with either."""
+    g = synth.make_config("c3_100k")
+    ref = oracle.sparse_optimize(util.to_oracle(g), 12, pcg_tol=1e-12, precond="amg")
+    o = HipOptimizer(pcg_rel_tol=1e-10)
+    try:
+        o.set_graph(g)
+        r = o.optimize(12)
+        v = o.vertices()
+        _, _, chi_dev = o.linearize()
+    finally:
+        o.close()
+    assert (r["iters"], r["stop"]) == (ref["iters"], ref["stop"]) and r["fallbacks"] == 0
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-6)
+    assert abs(r["chi2"][-1] - ref["chi2"][-1]) <= 1e-8 * ref["chi2"][-1]           # measured: ~1e-11
+    assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-6                  # measured: ~1e-9
+    gf = g.copy(); gf.v_pos[:] = v
+    chi_np = independent.Linearisation(gf).chi2
+    assert abs(chi_dev - chi_np) <= 1e-9 * chi_np

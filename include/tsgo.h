@@ -138,6 +138,13 @@ int tsgo_solve_step(tsgo_optimizer* opt, double* delta_out, double* chi2_out, in
  * other ranks (any transport); every rank then calls tsgo_comm_init.  Collectives are RCCL. */
 int tsgo_comm_unique_id(uint8_t id_out[128]);
 int tsgo_comm_init(tsgo_optimizer* opt, const uint8_t id[128]);
+/* The same sharded path among handles of ONE process (one thread per handle; they may share a device): the all-reduces
+ * go through host memory instead of RCCL.  For tests on a box with a single GPU, where RCCL refuses two ranks on one
+ * device — it is what lets `world` = 2, 3 run the device kernels' ownership rules there.  The group outlives its handles. */
+typedef struct tsgo_local_group tsgo_local_group;
+int tsgo_local_group_create(int32_t world, tsgo_local_group** out);
+void tsgo_local_group_destroy(tsgo_local_group* group);
+int tsgo_comm_init_local(tsgo_optimizer* opt, tsgo_local_group* group);
 
 /* Timing probe used by bench.py: average device time (hipEvent, microseconds) of `reps` back-to-back
  * launches of one kernel on the handle's stream, and the algorithmic bytes one launch moves.

@@ -1,0 +1,92 @@
+"""The edge-sharded DEVICE path with 2 and 3 ranks on the one GPU a box has (`-m gpu`).  RCCL refuses two ranks on one device,
+so the handles of this process (one thread each) are joined by the library's in-process all-reduce group
+(tsgo_comm_init_local: same places, same buffers as the RCCL calls, through host memory).  What this covers that a one-rank
+communicator cannot: per-shard slot tables, which rank applies a pose's diagonal block / gauge / damping, rank 0 alone
+contributing the level-0 diagonal, per-rank level-0 contribution lists, partial products and partial dots."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests import util
+from toyslam_amd import synth
+from toyslam_amd.optimizer import HipOptimizer, free_local_group, local_group
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_sharded(g, world, iterations, **kw):
+    group = local_group(world)
+    out, errs = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            o = HipOptimizer(rank=rank, world=world, **kw)
+            try:
+                o.comm_init_local(group)
+                o.set_graph(g)
+                r = o.optimize(iterations)
+                out[rank] = (r, o.vertices())
+            finally:
+                o.close()
+        except Exception as e:                       # noqa: BLE001 - reported by the caller
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(k,), daemon=True) for k in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    assert not any(t.is_alive() for t in th), "a rank is stuck in the in-process all-reduce (another one left early?)"
+    free_local_group(group)
+    return out
+
+
+def _merge_landmarks(g, outs):
+    """Landmarks are shard-local: every rank returns its own; poses are replicated."""
+    v = outs[0][1].copy()
+    moved = np.zeros(len(g.v_id), bool)
+    for _, vr in outs:
+        m = np.any(vr != g.v_pos, axis=1) & (g.v_type == 1)
+        assert not np.any(moved & m), "a landmark was updated by two ranks"
+        v[m] = vr[m]; moved |= m
+    return v
+
+
+@pytest.mark.parametrize("world,precond", [(2, "amg"), (3, "amg"), (2, "jacobi")])
+def test_sharded_device_run_matches_the_single_handle_run(world, precond):
+    g = synth.make(6000, 10, loop_closures=40, seed=13)
+    g.fixed = np.array([0, int(g.v_id[4000]), int(g.v_id[-5])], np.uint32)       # a fixed pose in another shard's range, a fixed landmark
+    single = HipOptimizer(pcg_rel_tol=1e-12, preconditioner=precond)
+    try:
+        single.set_graph(g); rs = single.optimize(5); vs = single.vertices()
+    finally:
+        single.close()
+    outs = _run_sharded(g, world, 5, pcg_rel_tol=1e-12, preconditioner=precond)
+    for r, _ in outs:
+        np.testing.assert_allclose(r["chi2"], rs["chi2"], rtol=1e-10)
+        np.testing.assert_array_equal(r["chi2"], outs[0][0]["chi2"])            # the ranks agree bit for bit ...
+        np.testing.assert_array_equal(r["cg_iters"], outs[0][0]["cg_iters"])    # ... and take the same decisions
+        assert r["fallbacks"] == 0
+        assert abs(r["delta_norm"] - rs["delta_norm"]) <= 1e-9 * rs["delta_norm"]
+        if precond == "amg":
+            assert r["cg_iters"].max() < 60 and np.all(np.abs(r["cg_iters"] - rs["cg_iters"]) <= 3), (r["cg_iters"], rs["cg_iters"])
+    v = _merge_landmarks(g, outs)
+    assert util.max_vertex_diff(v, vs, g.v_type) < 1e-8
+    ref = oracle.sparse_optimize(util.to_oracle(g), 5, pcg_tol=1e-12, precond="amg")
+    assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-7
+
+
+def test_sharded_device_run_with_python_rules_and_analytic_jacobians():
+    g = synth.make(4000, 8, loop_closures=60, seed=17)
+    oracle.set_odom_jacobian("analytic")
+    try:
+        ref = oracle.sparse_optimize(util.to_oracle(g), 4, pcg_tol=1e-12, precond="amg", rules="python", lr=0.6)
+    finally:
+        oracle.set_odom_jacobian("constant")
+    outs = _run_sharded(g, 2, 4, pcg_rel_tol=1e-12, rules="python", lr=0.6, odom_jacobian="analytic")
+    for r, _ in outs:
+        np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
+    assert util.max_vertex_diff(_merge_landmarks(g, outs), ref["v_pos"], g.v_type) < 1e-7

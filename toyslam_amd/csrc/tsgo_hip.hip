@@ -83,6 +83,28 @@ using namespace tsgo;
         }                                                                                              \
     } while (0)
 
+}  // namespace
+
+// An all-reduce among engine handles of ONE process (typically sharing one device): every rank stages its buffer in host
+// memory, all ranks meet, every rank sums the staged buffers in rank order (same bits everywhere, as with RCCL) and copies
+// the sum back.  Slow by design; it exists so that the edge-sharded device path (shard tables, ownership rules, per-rank
+// level-0 lists, where the all-reduces sit) can be run with 2, 3, ... ranks on a box with a single GPU, where RCCL refuses
+// two ranks on one device.  tests/test_gpu_sharded_inprocess.py.
+struct tsgo_local_group {
+    int world = 1;
+    std::mutex m; std::condition_variable cv;
+    int arrived = 0; long generation = 0;
+    std::vector<std::vector<unsigned char>> stage;
+    void barrier() {
+        std::unique_lock<std::mutex> l(m);
+        const long gen = generation;
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
+        else cv.wait(l, [&] { return generation != gen; });
+    }
+};
+
+namespace {
+
 struct IEngine {
     virtual ~IEngine() {}
     virtual int set_graph(const tsgo_graph& g) = 0;
@@ -93,6 +115,7 @@ struct IEngine {
     virtual int time_kernel(int which, int reps, double* us, double* bytes) = 0;
     virtual int cycle_probe(int reps, tsgo_cycle_level* out, int cap) = 0;
     ncclComm_t comm = nullptr;
+    tsgo_local_group* lgroup = nullptr;      // in-process stand-in for the communicator (tests on a one-GPU box)
 };
 
 constexpr int kRhoSteps = 16, kRhoBlocks = 64, kRhoEvery = 8;   // smoother-damping estimate: power steps, partial sums, refresh period
@@ -834,15 +857,35 @@ template <typename T> struct Engine : IEngine {
     // The collective path (eager launches, block-Jacobi PCG, all-reduces between kernels) is taken by every shard of a
     // split graph — and by a single shard that was given a communicator (tsgo_comm_init with world = 1), which is how
     // the RCCL plumbing is exercised on a one-GPU box.
-    bool collective() const { return pr.world > 1 || comm != nullptr; }
+    bool collective() const { return pr.world > 1 || comm != nullptr || lgroup != nullptr; }
+    template <typename U> int allreduce_local(U* buf, size_t n) {
+        tsgo_local_group& G = *lgroup;
+        std::vector<unsigned char>& mine = G.stage[cfg.rank];
+        mine.resize(n * sizeof(U));
+        HIP_OK(hipMemcpyAsync(mine.data(), buf, n * sizeof(U), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        G.barrier();                                   // every rank's contribution is staged
+        std::vector<U> sum(n, U(0));
+        for (int r = 0; r < G.world; ++r) {
+            if (G.stage[r].size() != n * sizeof(U)) return set_error(-12, "in-process all-reduce: ranks disagree on the buffer size");
+            const U* src = (const U*)G.stage[r].data();
+            for (size_t k = 0; k < n; ++k) sum[k] += src[k];
+        }
+        G.barrier();                                   // nobody restages while another rank still reads
+        HIP_OK(hipMemcpyAsync(buf, sum.data(), n * sizeof(U), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        return 0;
+    }
     int allreduce(T* buf, size_t n) {
         if (!collective()) return 0;
+        if (lgroup) return allreduce_local(buf, n);
         if (!comm) return set_error(-12, "world > 1 but tsgo_comm_init was not called");
         NCCL_OK(ncclAllReduce(buf, buf, n, sizeof(T) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream));
         return 0;
     }
     int allreduce_h(H* buf, size_t n) {       // hierarchy storage type (f32 unless TSGO_HIER_F64)
         if (!collective()) return 0;
+        if (lgroup) return allreduce_local(buf, n);
         if (!comm) return set_error(-12, "world > 1 but tsgo_comm_init was not called");
         NCCL_OK(ncclAllReduce(buf, buf, n, sizeof(H) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream));
         return 0;
@@ -1309,6 +1352,19 @@ int tsgo_time_kernel(tsgo_optimizer* o, int32_t which, int32_t reps, double* us,
 int tsgo_cycle_probe(tsgo_optimizer* o, int32_t reps, tsgo_cycle_level* out, int32_t cap) {
     if (!o || !out || reps <= 0 || cap <= 0) return tsgo::set_error(-1, "tsgo_cycle_probe: bad argument");
     return o->eng->cycle_probe(reps, out, cap);
+}
+int tsgo_local_group_create(int32_t world, tsgo_local_group** out) {
+    if (!out || world < 1) return tsgo::set_error(-1, "tsgo_local_group_create: bad argument");
+    auto* g = new tsgo_local_group(); g->world = world; g->stage.resize(world);
+    *out = g;
+    return 0;
+}
+void tsgo_local_group_destroy(tsgo_local_group* g) { delete g; }
+int tsgo_comm_init_local(tsgo_optimizer* o, tsgo_local_group* g) {
+    if (!o || !g) return tsgo::set_error(-1, "tsgo_comm_init_local: null argument");
+    if (o->cfg.world != g->world || o->cfg.rank < 0 || o->cfg.rank >= g->world) return tsgo::set_error(-1, "tsgo_comm_init_local: the handle's rank / world do not fit the group");
+    o->eng->lgroup = g;
+    return 0;
 }
 int tsgo_comm_unique_id(uint8_t id_out[128]) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");

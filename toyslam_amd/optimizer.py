@@ -94,6 +94,10 @@ class HipOptimizer:
         _lib.check(self.lib, min(n, 0), "tsgo_cycle_probe")
         return [(arr[k].us_per_sweep, arr[k].bytes_per_sweep, arr[k].sweeps_per_cycle) for k in range(n)]
 
+    def comm_init_local(self, group):
+        """group: a handle from local_group(world) shared by the handles of this process (one thread each)."""
+        _lib.check(self.lib, self.lib.tsgo_comm_init_local(self.h, group), "tsgo_comm_init_local")
+
     def comm_unique_id(self):
         buf = (C.c_uint8 * 128)()
         _lib.check(self.lib, self.lib.tsgo_comm_unique_id(buf), "tsgo_comm_unique_id")
@@ -102,6 +106,18 @@ class HipOptimizer:
     def comm_init(self, uid: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         _lib.check(self.lib, self.lib.tsgo_comm_init(self.h, buf), "tsgo_comm_init")
+
+
+def local_group(world):
+    """An in-process all-reduce group for `world` HipOptimizer handles (tests of the sharded path on a one-GPU box)."""
+    lib = _lib.hip_lib()
+    g = C.c_void_p()
+    _lib.check(lib, lib.tsgo_local_group_create(world, C.byref(g)), "tsgo_local_group_create")
+    return g
+
+
+def free_local_group(group):
+    _lib.hip_lib().tsgo_local_group_destroy(group)
 
 
 class GraphOptimizer:

@@ -122,7 +122,8 @@ int tsgo_optimize(tsgo_optimizer* opt, int32_t iterations, tsgo_stats* stats);
 
 /* Replaces GraphGpu::ToHost (remote/cuda/graph/GraphGpu.h:190-224) / the vertex read-out of
  * SerializeGraphFuncCpu::SerializeVertex (remote/serialization/SerializeGraphFuncCpu.h:10-41):
- * v_pos_out has 3 doubles per vertex in the order of tsgo_graph.v_id; theta = atan2(R10, R00). */
+ * v_pos_out has 3 doubles per vertex in the order of tsgo_graph.v_id; theta = atan2(R10, R00).  A shard (world > 1)
+ * writes every pose and the landmarks IT owns; the entries of the other shards' landmarks are left untouched. */
 int tsgo_get_vertices(tsgo_optimizer* opt, double* v_pos_out);
 
 /* Parity probes (no reference counterpart; they expose what OptimizerCpu.h:82-138 builds).

@@ -37,6 +37,7 @@ class HipOptimizer:
         self.h = C.c_void_p()
         _lib.check(self.lib, self.lib.tsgo_create(C.byref(cfg), C.byref(self.h)), "tsgo_create")
         self.n_vertices = 0
+        self._v_in = None
 
     def close(self):
         if self.h:
@@ -53,6 +54,7 @@ class HipOptimizer:
         cg = g.c_struct()
         _lib.check(self.lib, self.lib.tsgo_set_graph(self.h, C.byref(cg)), "tsgo_set_graph")
         self.n_vertices = len(g.v_id)
+        self._v_in = g.v_pos.copy() if self.cfg.world > 1 else None    # a shard returns its own landmarks; the others keep their input
 
     def optimize(self, iterations):
         st = _lib.tsgo_stats()
@@ -65,7 +67,7 @@ class HipOptimizer:
                     cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks)
 
     def vertices(self):
-        out = np.zeros((self.n_vertices, 3))
+        out = np.zeros((self.n_vertices, 3)) if self._v_in is None else np.ascontiguousarray(self._v_in.copy())
         _lib.check(self.lib, self.lib.tsgo_get_vertices(self.h, out.ctypes.data), "tsgo_get_vertices")
         return out
 

@@ -90,3 +90,44 @@ def test_sharded_device_run_with_python_rules_and_analytic_jacobians():
     for r, _ in outs:
         np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
     assert util.max_vertex_diff(_merge_landmarks(g, outs), ref["v_pos"], g.v_type) < 1e-7
+
+
+def test_bench_probe_sequence_of_a_sharded_run_does_not_deadlock():
+    """bench.py --gpus N (N > 1) runs, on EVERY rank, timed steps, the kernel probes (each linearises, i.e. all-reduces), the
+    coarse-level probe, the whole-iteration and setup probes, a second set_graph (structure reuse) and the 50-iteration
+    convergence run.  The same sequence with three in-process ranks: every rank must come back, with the same numbers where
+    they are replicated."""
+    g = synth.make(5000, 10, seed=19)
+    world = 3
+    group = local_group(world)
+    res, errs = [None] * world, []
+
+    def rank_main(rank):
+        try:
+            o = HipOptimizer(rank=rank, world=world, pcg_rel_tol=1e-10)
+            try:
+                o.comm_init_local(group)
+                o.set_graph(g)
+                chi = [o.optimize(1)["chi2"][0] for _ in range(3)]
+                probes = [o.time_kernel(w, reps=5)[0] for w in (0, 1, 2, 3, 4)]
+                levels = o.level_sweep_times(reps=5)
+                it_us = o.time_kernel(5, reps=3)[0]; setup_us = o.time_kernel(6, reps=2)[0]
+                o.set_graph(g)
+                r = o.optimize(8)
+                res[rank] = (chi, r["chi2"], r["structure_reused"], len(levels), it_us > 0 and setup_us > 0 and min(probes) > 0)
+            finally:
+                o.close()
+        except Exception as e:                       # noqa: BLE001
+            errs.append((rank, repr(e)))
+
+    th = [threading.Thread(target=rank_main, args=(k,), daemon=True) for k in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not errs, errs
+    assert not any(t.is_alive() for t in th), "deadlock: a rank did not come back"
+    free_local_group(group)
+    for k in range(1, world):
+        assert res[k][0] == res[0][0] and np.array_equal(res[k][1], res[0][1])
+    assert all(r[2] and r[3] >= 1 and r[4] for r in res)

@@ -131,3 +131,20 @@ def test_bench_probe_sequence_of_a_sharded_run_does_not_deadlock():
     for k in range(1, world):
         assert res[k][0] == res[0][0] and np.array_equal(res[k][1], res[0][1])
     assert all(r[2] and r[3] >= 1 and r[4] for r in res)
+
+
+@pytest.mark.parametrize("case", ["pose_graph_without_landmarks", "near_optimum", "fixed_landmark_and_duplicate_fixed_ids", "self_loop_and_duplicate_edges", "isolated_vertices"])
+def test_sharded_stop_rules_and_degenerate_shards(case):
+    """Every way out of the loop, with two ranks: 'worse' (the landmark-norm reduction is then owed after the loop), 'converged'
+    (the reduction that decides it runs only when the pose part is already small), the cap; shards that own no landmark at
+    all; a fixed landmark; duplicate edges.  Against the dense cpu/eigen restatement."""
+    from tests import edge_cases
+    g = getattr(edge_cases, case)()
+    ref = oracle.optimize(util.to_oracle(g), 30, mode="cpp", solver="qr")        # rank-revealing, like the reference (isolated vertices make H singular)
+    outs = _run_sharded(g, 2, 30, pcg_rel_tol=1e-12)
+    for r, _ in outs:
+        assert (r["iters"], r["stop"]) == (ref["iters"], ref["stop"]), (case, r["stop"], r["iters"], ref["stop"], ref["iters"])
+        np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-8)
+        assert abs(r["delta_norm"] - ref["delta_norm"]) <= 1e-7 * max(1.0, ref["delta_norm"])
+    scale = max(1.0, float(np.abs(ref["v_pos"]).max()))
+    assert util.max_vertex_diff(_merge_landmarks(g, outs), ref["v_pos"], g.v_type) < 1e-7 * scale

@@ -1,7 +1,10 @@
 // server.cpp — `graph_optimizer`: drop-in for ToySlam's remote optimizer process.
 //
 //   graph_optimizer [HOST=127.0.0.1] [PORT=8888] [ITERATIONS=10] [PIPELINE=cpu] [SOLVER=eigen]
-//                   [PRECISION=64] [PCG_TOL=1e-10] [DEVICE=0] [ENGINES=2]
+//                   [PRECISION=64] [PCG_TOL=1e-10] [DEVICE=0] [ENGINES=2] [RULES=cpp] [ODOM_JACOBIAN=constant]
+//   RULES "python" or "python:LR": the loop of the reference's in-process Python optimizer instead (lambda * I damping, step LR,
+//   default 0.2 as slam_main.py passes); ODOM_JACOBIAN "analytic": the extension of tsgo_config.odom_jacobian.  Both default to
+//   what the reference's C++ server does.
 //
 // Positional arguments 1-5 are the reference's (remote/app/main.cpp:12-16, README.md:15-18).  The
 // reference maps PIPELINE "cpu" -> CPU optimizer and anything else -> GPU, SOLVER "eigen" -> Eigen and
@@ -209,6 +212,8 @@ int main(int argc, char* argv[]) {
         const double tol = argc < 8 ? 1e-10 : std::stod(argv[7]);
         const int device = argc < 9 ? 0 : std::stoi(argv[8]);
         const int engines = argc < 10 ? 2 : std::max(1, std::stoi(argv[9]));
+        const std::string rulesS = argc < 11 ? "cpp" : argv[10];
+        const std::string odomS = argc < 12 ? "constant" : argv[11];
         // the reference prints the enums after forcing them to what the build supports (main.cpp:21-34):
         // 0 = EIGEN, 1 = CUDA; here both are always the accelerator pipeline.
         std::cout << "iters: " << iters << ", optimizerType: 1, solverType: 1" << std::endl;
@@ -218,6 +223,13 @@ int main(int argc, char* argv[]) {
 
         tsgo_config cfg; tsgo_default_config(&cfg);
         cfg.device = device; cfg.precision = precision; cfg.pcg_rel_tol = tol;
+        if (rulesS.rfind("python", 0) == 0) {
+            cfg.rules = 1;
+            const size_t colon = rulesS.find(':');
+            if (colon != std::string::npos) cfg.lr = std::stod(rulesS.substr(colon + 1));
+            std::cout << "rules: python/optimizer/graph_optimizer.py (lambda * I, lr " << cfg.lr << ")\n";
+        }
+        if (odomS == "analytic") { cfg.odom_jacobian = 1; std::cout << "ODOM Jacobians: analytic (extension)\n"; }
         Server srv; srv.iterations = iters; srv.cfg = cfg; srv.max_engines = engines;
         {   // fail at start-up, like the reference, when the pipeline cannot be created at all
             tsgo_optimizer* first = srv.acquire();

@@ -30,7 +30,8 @@ template <typename V> struct Raw {
     std::unique_ptr<V[]> p; size_t n = 0, cap = 0;
     // grow-only: a handle that is decoded into again (tsgo_wire_decode_into) keeps its pages — fresh pages for 120 MB cost more
     // than parsing into them
-    void alloc(size_t count) { if (count > cap || !p) { cap = count ? count : 1; p.reset(new V[cap]); } n = count; }
+    // (a quarter of headroom when it must grow: a front-end that appends a few poses per message then reallocates rarely)
+    void alloc(size_t count) { if (count > cap || !p) { cap = count + count / 4 + 1; p.reset(new V[cap]); } n = count; }
     V* data() { return p.get(); } const V* data() const { return p.get(); }
     size_t size() const { return n; }
     V& operator[](size_t k) { return p[k]; } const V& operator[](size_t k) const { return p[k]; }

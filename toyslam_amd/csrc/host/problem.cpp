@@ -2,7 +2,9 @@
 #include "problem.h"
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <numeric>
 #include <unordered_map>
@@ -93,6 +95,14 @@ inline size_t slot_of(const SellTable& t, int v, int k) {
 }  // namespace
 
 std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem& out) {
+    static const bool timing = getenv("TSGO_LAYOUT_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        if (!timing) return;
+        const auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[layout] %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t_last).count());
+        t_last = n;
+    };
     Problem pr;
     pr.rank = opt.rank; pr.world = std::max(1, opt.world);
     if (pr.rank < 0 || pr.rank >= pr.world) return "rank outside [0, world)";
@@ -127,6 +137,7 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
     const int P = (int)pose_pos.size(), Lt = (int)lm_pos.size();
     pr.P = P; pr.L_total = Lt;
 
+    lap("classify vertices");
     // ---- validate edges, degrees -------------------------------------------------------------------
     std::vector<int> ev1(nE), ev2(nE);        // vertex positions of the endpoints
     std::vector<int> deg_pose_lm(P, 0), deg_lm(Lt, 0), deg_pose_od(P, 0);
@@ -147,6 +158,7 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
         } else return "unknown edge type " + std::to_string(t);
     }
 
+    lap("validate edges, degrees");
     // ---- shard: contiguous landmark range balanced by LM-edge count; contiguous pose range --------
     {
         const int64_t total = pr.n_lm_edges_total;
@@ -203,6 +215,7 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
         }
     }
 
+    lap("numbering, windows, state");
     // ---- per-vertex degrees in internal numbering (owned edges only) ---------------------------------
     std::vector<int> dP(P, 0), dL(L, 0), dO(P, 0);
     for (int e = 0; e < nE; ++e) {
@@ -225,6 +238,7 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
     shape_table(pr.by_lm, Gl, dL, LM_PLANES, opt.fill_planes);
     shape_table(pr.odom, Gp, dO, OD_PLANES, opt.fill_planes);
 
+    lap("owned degrees, table shapes");
     // ---- fill ----------------------------------------------------------------------------------------
     std::vector<int> fillP(P, 0), fillL(L, 0), fillO(P, 0);
     for (int e = 0; e < nE; ++e) {
@@ -259,7 +273,9 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
             }
         }
     }
+    lap("fill slots");
     out = std::move(pr);
+    lap("hand over (frees the old)");
     return std::string();
 }
 

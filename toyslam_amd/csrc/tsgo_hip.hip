@@ -253,6 +253,7 @@ template <typename T> struct Engine : IEngine {
     int stage_reserve(size_t n) {
         if (n <= stage_cap) return 0;
         if (stage) { (void)hipHostFree(stage); stage = nullptr; stage_cap = 0; }
+        n += n / 4;                               // headroom for a growing graph: pinning memory is the expensive part
         HIP_OK(hipHostMalloc((void**)&stage, n * sizeof(T)));
         stage_cap = n;
         return 0;

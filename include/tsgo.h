@@ -223,6 +223,8 @@ typedef struct tsgo_amg_info {
     int64_t schur_contribs;         /* landmark-pair terms summed into the explicit level-0 matrix */
     double ms_layout, ms_symbolic;  /* host time: slot tables / hierarchy patterns */
     int32_t agg_min[8], agg_max[8]; /* smallest / largest aggregate (in nodes of that level) leaving each level */
+    uint64_t checksum;              /* FNV-1a over every slot table, numbering, pattern and gather list, in order: equal checksums
+                                     * = the device would be handed the same bytes (the build must not depend on the thread count) */
 } tsgo_amg_info;
 int tsgo_amg_probe(const tsgo_graph* g, tsgo_amg_info* out);
 /* The same for shard `rank` of `world` (edge-sharded runs replicate the hierarchy; only the level-0 contribution lists

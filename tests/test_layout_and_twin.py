@@ -259,3 +259,30 @@ def test_twin_python_rules_reproduce_the_reference_python_optimizer():
     r1 = oracle.sparse_optimize(util.to_oracle(g), 6, pcg_tol=1e-13, precond="amg", rules="python", lr=1.0)
     assert r1["iters"] == rd["iters"] and r1["stop"] == rd["stop"]
     np.testing.assert_allclose(r1["chi2"], rd["chi2"], rtol=1e-9)
+
+
+def test_layout_and_patterns_do_not_depend_on_the_host_thread_count():
+    """The slot fill (host/problem.cpp) and the pattern builder (host/amg.cpp) split their work over host threads; the k-th
+    edge of a vertex in input order must still take the vertex's k-th slot and every list keep its order, or summation
+    orders on the device — and with them the bits of every result — would depend on the machine.  tsgo_amg_info.checksum
+    hashes every table, numbering, pattern and gather list: 330 k edges (several fill chunks), 1 / 2 / 5 / 16 threads, whole
+    graph and one shard of three."""
+    import os
+    g = synth.make(30000, 10, loop_closures=200, seed=9)
+    lib = _lib.host_lib(); cg = g.c_struct()
+    saved = os.environ.get("TSGO_HOST_THREADS")
+    sums = {}
+    try:
+        for threads in ("1", "2", "5", "16"):
+            os.environ["TSGO_HOST_THREADS"] = threads
+            for rank, world in ((0, 1), (1, 3)):
+                info = _lib.tsgo_amg_info(); od = C.c_int64()
+                _lib.check(lib, lib.tsgo_amg_probe_shard(C.byref(cg), rank, world, C.byref(info), C.byref(od)), "tsgo_amg_probe_shard")
+                sums.setdefault((rank, world), set()).add(info.checksum)
+    finally:
+        if saved is None:
+            os.environ.pop("TSGO_HOST_THREADS", None)
+        else:
+            os.environ["TSGO_HOST_THREADS"] = saved
+    assert all(len(v) == 1 for v in sums.values()), sums
+    assert sums[(0, 1)] != sums[(1, 3)]

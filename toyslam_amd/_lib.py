@@ -44,7 +44,7 @@ class tsgo_layout_info(C.Structure):
 class tsgo_amg_info(C.Structure):
     _fields_ = [("n_levels", C.c_int32), ("rows", C.c_int64 * 8), ("blocks", C.c_int64 * 8), ("p_blocks", C.c_int64 * 8),
                 ("schur_contribs", C.c_int64), ("ms_layout", C.c_double), ("ms_symbolic", C.c_double),
-                ("agg_min", C.c_int32 * 8), ("agg_max", C.c_int32 * 8)]
+                ("agg_min", C.c_int32 * 8), ("agg_max", C.c_int32 * 8), ("checksum", C.c_uint64)]
 
 
 HOST_SYMBOLS = ["tsgo_default_config", "tsgo_last_error", "tsgo_wire_decode", "tsgo_wire_new", "tsgo_wire_decode_into", "tsgo_wire_view", "tsgo_wire_free",

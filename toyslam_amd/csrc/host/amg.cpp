@@ -5,6 +5,7 @@
 #include <sched.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -39,27 +40,31 @@ struct Stopwatch {
 struct Triple { int c, x, y; };
 inline bool triple_less(const Triple& p, const Triple& q) { return p.c != q.c ? p.c < q.c : (p.x != q.x ? p.x < q.x : p.y < q.y); }
 
-template <typename D, typename S> void append(D& dst, const S& src) { dst.insert(dst.end(), src.begin(), src.end()); }
-
 // Row-wise grouped output of a symbolic product, built per chunk and concatenated in row order.
 struct RowsOut {
     std::vector<int> row_nnz, col, grp_len, x, y, flag;
 };
+// The chunks' outputs land at offsets known from their sizes alone, so they are copied side by side (the serial version of
+// this spent more time than the chunks took to produce: 43 M list entries at 100k poses).
 void concat(std::vector<RowsOut>& parts, int used, BlockCsr& Z, PairList& pl, std::vector<int>* flag) {
-    Z.ptr.assign(1, 0); Z.col.clear(); pl.ptr.clear(); pl.ptr.push_back(0); pl.x.clear(); pl.y.clear();
-    if (flag) flag->clear();
-    size_t ncol = 0, npair = 0;
-    for (int c = 0; c < used; ++c) { ncol += parts[c].col.size(); npair += parts[c].x.size(); }
-    Z.col.reserve(ncol); pl.ptr.reserve(ncol + 1); pl.x.reserve(npair); pl.y.reserve(npair);
-    for (int c = 0; c < used; ++c) {
-        RowsOut& p = parts[c];
-        for (int nn : p.row_nnz) Z.ptr.push_back(Z.ptr.back() + nn);
-        append(Z.col, p.col);
-        for (int g : p.grp_len) pl.ptr.push_back(pl.ptr.back() + g);
-        append(pl.x, p.x); append(pl.y, p.y);
-        if (flag) append(*flag, p.flag);
-        p = RowsOut();
-    }
+    std::vector<size_t> r0(used + 1, 0), c0(used + 1, 0), p0(used + 1, 0);
+    for (int c = 0; c < used; ++c) { r0[c + 1] = r0[c] + parts[c].row_nnz.size(); c0[c + 1] = c0[c] + parts[c].col.size(); p0[c + 1] = p0[c] + parts[c].x.size(); }
+    Z.ptr.resize(r0[used] + 1); Z.col.resize(c0[used]); pl.ptr.resize(c0[used] + 1); pl.x.resize(p0[used]); pl.y.resize(p0[used]);
+    if (flag) flag->resize(c0[used]);
+    Z.ptr[0] = 0; pl.ptr[0] = 0;
+    parallel_chunks(used, [&](int, int cb, int ce) {
+        for (int c = cb; c < ce; ++c) {
+            RowsOut& p = parts[c];
+            int at = (int)c0[c];
+            for (size_t k = 0; k < p.row_nnz.size(); ++k) Z.ptr[r0[c] + k + 1] = (at += p.row_nnz[k]);
+            std::copy(p.col.begin(), p.col.end(), Z.col.begin() + c0[c]);
+            int pa = (int)p0[c];
+            for (size_t k = 0; k < p.grp_len.size(); ++k) pl.ptr[c0[c] + k + 1] = (pa += p.grp_len[k]);
+            std::copy(p.x.begin(), p.x.end(), pl.x.begin() + p0[c]); std::copy(p.y.begin(), p.y.end(), pl.y.begin() + p0[c]);
+            if (flag) std::copy(p.flag.begin(), p.flag.end(), flag->begin() + c0[c]);
+            p = RowsOut();
+        }
+    }, 1);
 }
 // sorted triples of one row -> grouped output
 inline void emit_row(std::vector<Triple>& row, RowsOut& o) {
@@ -150,16 +155,18 @@ std::string spgemm_sym(const BlockCsr& X, const std::vector<int>* x_alias, const
     sw3.lap("    spgemm fill pass");
     if (upper) {
         mirror->assign(nnz, -1);
-        bool ok = true;
-        for (int i = 0; i < n; ++i)
-            for (int z = Z.ptr[i]; z < Z.ptr[i + 1]; ++z) {
-                const int c = Z.col[z];
-                if (c >= i) continue;
-                const int* lo = Z.col.data() + Z.ptr[c]; const int* hi = Z.col.data() + Z.ptr[c + 1];
-                const int* f = std::lower_bound(lo, hi, i);
-                if (f == hi || *f != i) { ok = false; continue; }
-                (*mirror)[z] = (int)(f - Z.col.data());
-            }
+        std::atomic<bool> ok{true};
+        parallel_chunks(n, [&](int, int b, int e) {
+            for (int i = b; i < e; ++i)
+                for (int z = Z.ptr[i]; z < Z.ptr[i + 1]; ++z) {
+                    const int c = Z.col[z];
+                    if (c >= i) continue;
+                    const int* lo = Z.col.data() + Z.ptr[c]; const int* hi = Z.col.data() + Z.ptr[c + 1];
+                    const int* f = std::lower_bound(lo, hi, i);
+                    if (f == hi || *f != i) { ok = false; continue; }
+                    (*mirror)[z] = (int)(f - Z.col.data());
+                }
+        });
         if (!ok) return "the Galerkin pattern is not structurally symmetric";
     }
     return std::string();
@@ -178,8 +185,10 @@ void transpose_pattern(const BlockCsr& X, BlockCsr& Xt, std::vector<int>& to_src
 
 std::vector<int> find_diag(const BlockCsr& A) {
     std::vector<int> d(A.n_rows, -1);
-    for (int i = 0; i < A.n_rows; ++i)
-        for (int a = A.ptr[i]; a < A.ptr[i + 1]; ++a) if (A.col[a] == i) d[i] = a;
+    parallel_chunks(A.n_rows, [&](int, int b, int e) {
+        for (int i = b; i < e; ++i)
+            for (int a = A.ptr[i]; a < A.ptr[i + 1]; ++a) if (A.col[a] == i) d[i] = a;
+    }, 4096);
     return d;
 }
 
@@ -433,16 +442,29 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
             }
             parts[c] = std::move(o);
         });
-        L0.A.ptr.assign(1, 0); S.schur.ptr.assign(1, 0); S.schur.od_ptr.assign(1, 0);
+        // the chunks' outputs, side by side (offsets from their sizes)
+        std::vector<size_t> r0(used + 1, 0), c0(used + 1, 0), q0(used + 1, 0), d0(used + 1, 0);
         for (int c = 0; c < used; ++c) {
-            SOut& o = parts[c];
-            for (int nn : o.row_nnz) L0.A.ptr.push_back(L0.A.ptr.back() + nn);
-            append(L0.A.col, o.col);
-            for (int g : o.n_pair) S.schur.ptr.push_back(S.schur.ptr.back() + g);
-            for (int g : o.n_od) S.schur.od_ptr.push_back(S.schur.od_ptr.back() + g);
-            append(S.schur.slot_i, o.si); append(S.schur.slot_k, o.sk); append(S.schur.od_slot, o.os);
-            o = SOut();
+            r0[c + 1] = r0[c] + parts[c].row_nnz.size(); c0[c + 1] = c0[c] + parts[c].col.size();
+            q0[c + 1] = q0[c] + parts[c].si.size(); d0[c + 1] = d0[c] + parts[c].os.size();
         }
+        L0.A.ptr.resize(r0[used] + 1); L0.A.col.resize(c0[used]);
+        S.schur.ptr.resize(c0[used] + 1); S.schur.od_ptr.resize(c0[used] + 1);
+        S.schur.slot_i.resize(q0[used]); S.schur.slot_k.resize(q0[used]); S.schur.od_slot.resize(d0[used]);
+        L0.A.ptr[0] = 0; S.schur.ptr[0] = 0; S.schur.od_ptr[0] = 0;
+        parallel_chunks(used, [&](int, int cb, int ce) {
+            for (int c = cb; c < ce; ++c) {
+                SOut& o = parts[c];
+                int at = (int)c0[c];
+                for (size_t k = 0; k < o.row_nnz.size(); ++k) L0.A.ptr[r0[c] + k + 1] = (at += o.row_nnz[k]);
+                std::copy(o.col.begin(), o.col.end(), L0.A.col.begin() + c0[c]);
+                int qa = (int)q0[c], da = (int)d0[c];
+                for (size_t k = 0; k < o.n_pair.size(); ++k) { S.schur.ptr[c0[c] + k + 1] = (qa += o.n_pair[k]); S.schur.od_ptr[c0[c] + k + 1] = (da += o.n_od[k]); }
+                std::copy(o.si.begin(), o.si.end(), S.schur.slot_i.begin() + q0[c]); std::copy(o.sk.begin(), o.sk.end(), S.schur.slot_k.begin() + q0[c]);
+                std::copy(o.os.begin(), o.os.end(), S.schur.od_slot.begin() + d0[c]);
+                o = SOut();
+            }
+        }, 1);
     }
     sw.lap("S pattern + lists");
     if (progress && progress->schur_ready) progress->schur_ready();
@@ -471,15 +493,19 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
     WGraph wg; std::vector<int> wkey;
     if (matching) {
         const float w_od = getenv("TSGO_AGG_WOD") ? (float)atof(getenv("TSGO_AGG_WOD")) : kAggOdomWeight;
-        wg.n = P; wg.ptr.assign(1, 0);
-        for (int i = 0; i < P; ++i) {
-            for (int a = L0.A.ptr[i]; a < L0.A.ptr[i + 1]; ++a) {
-                if (L0.A.col[a] == i) continue;
-                const float w = (float)(S.schur.ptr[a + 1] - S.schur.ptr[a]) + w_od * (float)(S.schur.od_ptr[a + 1] - S.schur.od_ptr[a]);
-                wg.col.push_back(L0.A.col[a]); wg.w.push_back(w);
+        wg.n = P; wg.ptr.assign(P + 1, 0);
+        for (int i = 0; i < P; ++i) wg.ptr[i + 1] = wg.ptr[i] + (L0.A.ptr[i + 1] - L0.A.ptr[i] - 1);      // every row holds its diagonal block (emit_diag)
+        wg.col.resize(wg.ptr[P]); wg.w.resize(wg.ptr[P]);
+        parallel_chunks(P, [&](int, int b, int e) {
+            for (int i = b; i < e; ++i) {
+                int at = wg.ptr[i];
+                for (int a = L0.A.ptr[i]; a < L0.A.ptr[i + 1]; ++a) {
+                    if (L0.A.col[a] == i) continue;
+                    wg.col[at] = L0.A.col[a];
+                    wg.w[at++] = (float)(S.schur.ptr[a + 1] - S.schur.ptr[a]) + w_od * (float)(S.schur.od_ptr[a + 1] - S.schur.od_ptr[a]);
+                }
             }
-            wg.ptr.push_back((int)wg.col.size());
-        }
+        }, 4096);
         wkey = S.order;
         L0.n_agg = aggregate_by_matching(wg, wkey, agg0, L0.agg);
     } else {
@@ -490,20 +516,27 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
     AmgLevel cur = std::move(L0);
     for (;;) {
         if (cur.n <= kCoarsestMax) { S.A_last = cur.A; S.diag_last = find_diag(cur.A); break; }
+        // The NEXT level's aggregates depend on the contracted coupling graph alone (aggregate_by_matching leaves it in wg),
+        // not on the Galerkin pattern: they are matched by a helper thread while this level's products are laid out.
+        const int na = cur.n_agg;
+        const int aggc = agg_at(S.levels.size() + 1);
+        const bool match_next = matching && na > kCoarsestMax;
+        std::vector<int> next_agg; int next_n_agg = 0;
+        std::thread helper;
+        if (match_next) helper = std::thread([&] { next_n_agg = aggregate_by_matching(wg, wkey, aggc, next_agg); });
         BlockCsr A_next; std::vector<double> xy_next;
         const std::string cerr = coarsen(cur, xy, rigid, A_next, xy_next, (int)S.levels.size() < smooth_levels && (int)S.levels.size() >= smooth_from);
+        if (helper.joinable()) helper.join();
         if (!cerr.empty()) return cerr;
         sw.lap("coarsen level");
-        const int na = cur.n_agg;
         S.levels.push_back(std::move(cur));
         if (S.levels.size() >= 32) return "too many multigrid levels";
         if (progress && progress->level_ready) progress->level_ready((int)S.levels.size());
         cur = AmgLevel();
         cur.n = na; cur.A = std::move(A_next);
-        cur.agg.resize(na);
-        const int aggc = agg_at(S.levels.size());
-        if (matching && na > kCoarsestMax) cur.n_agg = aggregate_by_matching(wg, wkey, aggc, cur.agg);
+        if (match_next) { cur.agg = std::move(next_agg); cur.n_agg = next_n_agg; }
         else {
+            cur.agg.resize(na);
             for (int a = 0; a < na; ++a) cur.agg[a] = a / aggc;     // aggregates are numbered along the trajectory
             cur.n_agg = (na + aggc - 1) / aggc;
         }

@@ -29,6 +29,17 @@ extern "C" int tsgo_layout_probe(const tsgo_graph* g, int32_t rank, int32_t worl
     return 0;
 }
 
+namespace {
+struct Fnv {
+    uint64_t h = 1469598103934665603ull;
+    void bytes(const void* p, size_t n) { const unsigned char* b = (const unsigned char*)p; for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; } }
+    template <typename V> void vec(const V& v) { const uint64_t n = v.size(); bytes(&n, sizeof(n)); if (n) bytes(v.data(), n * sizeof(v[0])); }
+    void table(const tsgo::SellTable& t) { vec(t.row_off); vec(t.idx); vec(t.edge); }
+    void csr(const tsgo::BlockCsr& m) { vec(m.ptr); vec(m.col); }
+    void pairs(const tsgo::PairList& p) { vec(p.ptr); vec(p.x); vec(p.y); }
+};
+}  // namespace
+
 static int amg_probe(const tsgo_graph* g, int rank, int world, tsgo_amg_info* out, int64_t* odom_out) {
     std::memset(out, 0, sizeof(*out));
     tsgo::Problem pr; tsgo::BuildOptions bo; bo.rank = rank; bo.world = world;
@@ -55,6 +66,15 @@ static int amg_probe(const tsgo_graph* g, int rank, int world, tsgo_amg_info* ou
     out->n_levels = n;
     out->schur_contribs = (int64_t)amg.schur.slot_i.size();
     if (odom_out) *odom_out = (int64_t)amg.schur.od_slot.size();
+    Fnv f;
+    f.table(pr.by_pose); f.table(pr.by_lm); f.table(pr.odom); f.vec(pr.pose_vertex); f.vec(pr.lm_vertex); f.vec(pr.gauge_p); f.vec(pr.gauge_l);
+    f.vec(amg.order); f.vec(amg.schur.ptr); f.vec(amg.schur.slot_i); f.vec(amg.schur.slot_k); f.vec(amg.schur.od_ptr); f.vec(amg.schur.od_slot);
+    for (const auto& L : amg.levels) {
+        f.csr(L.A); f.vec(L.diag); f.vec(L.agg); f.vec(L.rel); f.vec(L.rig); f.csr(L.P); f.vec(L.p_self); f.pairs(L.p_src); f.csr(L.R); f.vec(L.r_to_p);
+        f.csr(L.T); f.pairs(L.t_src); f.pairs(L.a_src); f.vec(L.a_mirror);
+    }
+    f.csr(amg.A_last); f.vec(amg.diag_last);
+    out->checksum = f.h;
     return 0;
 }
 

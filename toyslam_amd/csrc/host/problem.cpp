@@ -1,8 +1,12 @@
 // problem.cpp — builds the device-ready layout (see problem.h) from a tsgo_graph.
 #include "problem.h"
+#include "parallel.h"
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <climits>
+#include <cstdint>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -61,10 +65,13 @@ std::vector<int> window_sort(const std::vector<int>& degree, int window) {
     std::vector<int> order(degree.size());
     std::iota(order.begin(), order.end(), 0);
     if (window <= 1) return order;
-    for (size_t b = 0; b < order.size(); b += (size_t)window) {
-        const size_t e = std::min(order.size(), b + (size_t)window);
-        std::stable_sort(order.begin() + b, order.begin() + e, [&](int x, int y) { return degree[x] > degree[y]; });
-    }
+    const int n_win = (int)((order.size() + (size_t)window - 1) / (size_t)window);
+    parallel_chunks(n_win, [&](int, int wb, int we) {           // windows are independent
+        for (int w = wb; w < we; ++w) {
+            const size_t b = (size_t)w * (size_t)window, e = std::min(order.size(), b + (size_t)window);
+            std::stable_sort(order.begin() + b, order.begin() + e, [&](int x, int y) { return degree[x] > degree[y]; });
+        }
+    }, 4);
     return order;
 }
 
@@ -217,18 +224,38 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
 
     lap("numbering, windows, state");
     // ---- per-vertex degrees in internal numbering (owned edges only) ---------------------------------
-    std::vector<int> dP(P, 0), dL(L, 0), dO(P, 0);
-    for (int e = 0; e < nE; ++e) {
-        if (g.e_type[e] == 1) {
-            const int c = cls[ev2[e]];
-            if (c < pr.lm_first || c >= pr.lm_last) continue;
-            ++dP[pose_internal[cls[ev1[e]]]]; ++dL[lm_internal[c - pr.lm_first]]; ++pr.n_lm_edges;
-        } else {
-            const int p1 = pose_internal[cls[ev1[e]]], p2 = pose_internal[cls[ev2[e]]];
-            if (p1 >= pr.pose_first && p1 < pr.pose_last) ++dO[p1];
-            if (p2 >= pr.pose_first && p2 < pr.pose_last) ++dO[p2];
+    // The k-th edge of a vertex IN INPUT ORDER takes the vertex's k-th slot (the order fixes every summation order on the
+    // device).  Edge chunks are counted side by side: a chunk's count per vertex, an exclusive prefix over the chunks, and
+    // the fill pass of a chunk starts every vertex at its prefix — the same slots as one walk over all edges.
+    const int nt = std::max(1, std::min(host_threads(), nE / 65536));
+    auto chunk_begin = [&](int c) { return (int)((int64_t)nE * c / nt); };
+    std::vector<std::vector<int>> cP(nt), cL(nt), cO(nt);
+    std::vector<int64_t> n_lm_chunk(nt, 0);
+    parallel_chunks(nt, [&](int, int cb, int ce) {
+        for (int c = cb; c < ce; ++c) {
+            std::vector<int>& kp = cP[c]; std::vector<int>& kl = cL[c]; std::vector<int>& ko = cO[c];
+            kp.assign(P, 0); kl.assign(L, 0); ko.assign(P, 0);
+            for (int e = chunk_begin(c); e < chunk_begin(c + 1); ++e) {
+                if (g.e_type[e] == 1) {
+                    const int cl = cls[ev2[e]];
+                    if (cl < pr.lm_first || cl >= pr.lm_last) continue;
+                    ++kp[pose_internal[cls[ev1[e]]]]; ++kl[lm_internal[cl - pr.lm_first]]; ++n_lm_chunk[c];
+                } else {
+                    const int p1 = pose_internal[cls[ev1[e]]], p2 = pose_internal[cls[ev2[e]]];
+                    if (p1 >= pr.pose_first && p1 < pr.pose_last) ++ko[p1];
+                    if (p2 >= pr.pose_first && p2 < pr.pose_last) ++ko[p2];
+                }
+            }
         }
-    }
+    }, 1);
+    for (int c = 0; c < nt; ++c) pr.n_lm_edges += n_lm_chunk[c];
+    std::vector<int> dP(P, 0), dL(L, 0), dO(P, 0);
+    auto prefix = [&](std::vector<std::vector<int>>& cnt, std::vector<int>& total) {      // cnt[c][v] := edges of v before chunk c
+        parallel_chunks((int)total.size(), [&](int, int b, int e) {
+            for (int v = b; v < e; ++v) { int acc = 0; for (int c = 0; c < nt; ++c) { const int k = cnt[c][v]; cnt[c][v] = acc; acc += k; } total[v] = acc; }
+        }, 4096);
+    };
+    prefix(cP, dP); prefix(cL, dL); prefix(cO, dO);
     int Gp = opt.lanes_per_pose, Gl = opt.lanes_per_lm;
     if (Gp == 0) Gp = auto_lanes_pose(P ? (double)pr.n_lm_edges / P : 0.0);
     if (Gl == 0) Gl = auto_lanes_lm(L ? (double)pr.n_lm_edges / L : 0.0);
@@ -240,39 +267,45 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
 
     lap("owned degrees, table shapes");
     // ---- fill ----------------------------------------------------------------------------------------
-    std::vector<int> fillP(P, 0), fillL(L, 0), fillO(P, 0);
-    for (int e = 0; e < nE; ++e) {
-        const double* m = g.e_meas + (size_t)e * 9;
-        const double* w = g.e_inf + (size_t)e * 3;
-        if (g.e_type[e] == 1) {
-            const int c = cls[ev2[e]];
-            if (c < pr.lm_first || c >= pr.lm_last) continue;
-            const int p = pose_internal[cls[ev1[e]]], l = lm_internal[c - pr.lm_first];
-            const size_t sp = slot_of(pr.by_pose, p, fillP[p]++), sl = slot_of(pr.by_lm, l, fillL[l]++);
-            pr.by_pose.idx[sp] = (uint32_t)l; pr.by_pose.edge[sp] = (uint32_t)e;
-            pr.by_lm.idx[sl] = (uint32_t)p; pr.by_lm.edge[sl] = (uint32_t)e;
-            if (opt.fill_planes) {
-                double vals[LM_PLANES];
-                lm_static(m, w, vals);
-                for (int k = 0; k < LM_PLANES; ++k) { pr.by_pose.plane(k)[sp] = vals[k]; pr.by_lm.plane(k)[sl] = vals[k]; }
-            }
-        } else {
-            double inv[9];
-            if (!invert3(m, inv)) return "ODOM edge " + std::to_string(e) + " has a singular measurement matrix";
-            const int p1 = pose_internal[cls[ev1[e]]], p2 = pose_internal[cls[ev2[e]]];
-            for (int side = 0; side < 2; ++side) {
-                const int self = side ? p2 : p1, other = side ? p1 : p2;
-                if (self < pr.pose_first || self >= pr.pose_last) continue;
-                const size_t so = slot_of(pr.odom, self, fillO[self]++);
-                pr.odom.idx[so] = (uint32_t)other | (side ? kDirBit : 0u);
-                pr.odom.edge[so] = (uint32_t)e;
-                if (opt.fill_planes) {
-                    for (int k = 0; k < 6; ++k) pr.odom.plane(OD_MI0 + k)[so] = inv[k];
-                    for (int k = 0; k < 3; ++k) pr.odom.plane(OD_W0 + k)[so] = w[k];
+    std::atomic<int> bad_edge{INT32_MAX};
+    parallel_chunks(nt, [&](int, int cb, int ce) {
+        for (int c = cb; c < ce; ++c) {
+            std::vector<int>& fillP = cP[c]; std::vector<int>& fillL = cL[c]; std::vector<int>& fillO = cO[c];
+            for (int e = chunk_begin(c); e < chunk_begin(c + 1); ++e) {
+                const double* m = g.e_meas + (size_t)e * 9;
+                const double* w = g.e_inf + (size_t)e * 3;
+                if (g.e_type[e] == 1) {
+                    const int cl = cls[ev2[e]];
+                    if (cl < pr.lm_first || cl >= pr.lm_last) continue;
+                    const int p = pose_internal[cls[ev1[e]]], l = lm_internal[cl - pr.lm_first];
+                    const size_t sp = slot_of(pr.by_pose, p, fillP[p]++), sl = slot_of(pr.by_lm, l, fillL[l]++);
+                    pr.by_pose.idx[sp] = (uint32_t)l; pr.by_pose.edge[sp] = (uint32_t)e;
+                    pr.by_lm.idx[sl] = (uint32_t)p; pr.by_lm.edge[sl] = (uint32_t)e;
+                    if (opt.fill_planes) {
+                        double vals[LM_PLANES];
+                        lm_static(m, w, vals);
+                        for (int k = 0; k < LM_PLANES; ++k) { pr.by_pose.plane(k)[sp] = vals[k]; pr.by_lm.plane(k)[sl] = vals[k]; }
+                    }
+                } else {
+                    double inv[9];
+                    if (!invert3(m, inv)) { int seen = bad_edge.load(); while (e < seen && !bad_edge.compare_exchange_weak(seen, e)) {} continue; }
+                    const int p1 = pose_internal[cls[ev1[e]]], p2 = pose_internal[cls[ev2[e]]];
+                    for (int side = 0; side < 2; ++side) {
+                        const int self = side ? p2 : p1, other = side ? p1 : p2;
+                        if (self < pr.pose_first || self >= pr.pose_last) continue;
+                        const size_t so = slot_of(pr.odom, self, fillO[self]++);
+                        pr.odom.idx[so] = (uint32_t)other | (side ? kDirBit : 0u);
+                        pr.odom.edge[so] = (uint32_t)e;
+                        if (opt.fill_planes) {
+                            for (int k = 0; k < 6; ++k) pr.odom.plane(OD_MI0 + k)[so] = inv[k];
+                            for (int k = 0; k < 3; ++k) pr.odom.plane(OD_W0 + k)[so] = w[k];
+                        }
+                    }
                 }
             }
         }
-    }
+    }, 1);
+    if (bad_edge.load() != INT32_MAX) return "ODOM edge " + std::to_string(bad_edge.load()) + " has a singular measurement matrix";
     lap("fill slots");
     out = std::move(pr);
     lap("hand over (frees the old)");

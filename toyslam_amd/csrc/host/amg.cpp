@@ -394,6 +394,7 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
     // observers of every landmark: (pose, by_pose slot of that edge)
     std::vector<int> obs_ptr(pr.L + 1, 0);
     std::vector<int> obs_pose; std::vector<uint32_t> obs_slot;
+    obs_pose.reserve((size_t)pr.n_lm_edges); obs_slot.reserve((size_t)pr.n_lm_edges);
     for (int l = 0; l < pr.L; ++l) {
         for_slots(pr.by_lm, l, [&](size_t k) { obs_pose.push_back((int)pr.by_lm.idx[k]); obs_slot.push_back(epos[pr.by_lm.edge[k]]); });
         obs_ptr[l + 1] = (int)obs_pose.size();

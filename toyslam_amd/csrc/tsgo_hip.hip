@@ -152,12 +152,13 @@ template <typename T> struct Engine : IEngine {
     tsgo_config cfg;
     Problem pr;
     hipStream_t stream = nullptr;
-    std::vector<void*> allocs;
-    // Device memory of one graph comes from ONE arena, bump-allocated: tsgo_set_graph with a new structure frees nothing
-    // and allocates nothing as long as the new graph fits (hipFree is synchronous and a request makes ~220 allocations).
-    // The first graph of a handle sizes it: its allocations are individual (and counted); the arena replaces them, with
-    // headroom for a growing graph, at the next rebuild.
-    char* arena = nullptr; size_t arena_cap = 0, arena_used = 0, bytes_wanted = 0;
+    // Device memory of a graph is bump-allocated from a few large slabs that the handle keeps: tsgo_set_graph with a new
+    // structure frees nothing and allocates nothing as long as the new graph fits in what an earlier one needed (hipFree is
+    // synchronous and a request makes ~230 allocations).  Slabs grow geometrically (64 MB ... 1 GB each) and are returned
+    // to the driver when the handle is destroyed.
+    struct Slab { char* base; size_t cap, used; };
+    std::vector<Slab> slabs; size_t slab_total = 0;
+    static constexpr size_t kSlabMin = size_t(64) << 20, kSlabMax = size_t(1) << 30;
     bool have_graph_data = false;
     double ms_setup = 0;
     // Structure of the graph the device tables were built for (a SLAM front-end resends the same
@@ -229,21 +230,12 @@ template <typename T> struct Engine : IEngine {
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
 
-    ~Engine() override { release(); if (arena) (void)hipFree(arena); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    ~Engine() override { release(); for (Slab& sl : slabs) (void)hipFree(sl.base); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
 
     void release() {
         if (amg_builder.joinable()) amg_builder.join();
         if (cg_graph) { (void)hipGraphExecDestroy(cg_graph); cg_graph = nullptr; }
-        for (void* a : allocs) (void)hipFree(a);
-        allocs.clear();
-        if (bytes_wanted > arena_cap) {           // the graph just released did not fit: a bigger arena for the next one
-            if (arena) (void)hipFree(arena);
-            arena = nullptr; arena_cap = 0;
-            const size_t want = bytes_wanted + bytes_wanted / 4 + (size_t(1) << 20);
-            void* ptr = nullptr;
-            if (hipMalloc(&ptr, want) == hipSuccess) { arena = (char*)ptr; arena_cap = want; }
-        }
-        arena_used = 0; bytes_wanted = 0;
+        for (Slab& sl : slabs) sl.used = 0;
         if (h_state) { (void)hipHostFree(h_state); h_state = nullptr; }
         if (h_scratch) { (void)hipHostFree(h_scratch); h_scratch = nullptr; }
         if (h_rho) { (void)hipHostFree(h_rho); h_rho = nullptr; }
@@ -277,14 +269,15 @@ template <typename T> struct Engine : IEngine {
     }
     int fill_zero(void* dst, size_t bytes) { HIP_OK(hipMemsetAsync(dst, 0, bytes, stream)); return 0; }
     template <typename U> int dalloc(U** out, size_t n) {
-        void* ptr = nullptr;
         const size_t bytes = (std::max<size_t>(n, 1) * sizeof(U) + 255) & ~size_t(255);
-        bytes_wanted += bytes;
-        if (arena && arena_used + bytes <= arena_cap) { *out = (U*)(arena + arena_used); arena_used += bytes; return 0; }
+        for (Slab& sl : slabs)
+            if (sl.used + bytes <= sl.cap) { *out = (U*)(sl.base + sl.used); sl.used += bytes; return 0; }
+        const size_t cap = std::max(bytes, std::min(kSlabMax, std::max(kSlabMin, slab_total)));
+        void* ptr = nullptr;
         const auto t0 = std::chrono::steady_clock::now();
-        HIP_OK(hipMalloc(&ptr, bytes));
+        HIP_OK(hipMalloc(&ptr, cap));
         ms_in_malloc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); ++n_malloc;
-        allocs.push_back(ptr);
+        slabs.push_back({(char*)ptr, cap, bytes}); slab_total += cap;
         *out = (U*)ptr;
         return 0;
     }
@@ -604,7 +597,7 @@ template <typename T> struct Engine : IEngine {
         have_graph_data = true;
         if (cfg.use_graphs && !collective()) { if (int rc = capture_cg_graph()) return rc; }
         lap("hipGraph capture");
-        if (say) std::fprintf(stderr, "[tsgo] set_graph: %d hipMalloc calls took %.1f ms in total\n", n_malloc, ms_in_malloc);
+        if (say) std::fprintf(stderr, "[tsgo] set_graph: %d slabs (%.0f MB) hold the graph; hipMalloc calls of this handle so far: %d, %.1f ms\n", (int)slabs.size(), slab_total / 1048576.0, n_malloc, ms_in_malloc);
         structure.take(g);
         ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return 0;

@@ -245,6 +245,30 @@ def test_same_structure_again_only_refills_values_and_equals_a_fresh_engine(prec
         o.close()
 
 
+def test_one_handle_through_graphs_of_very_different_sizes_equals_fresh_handles():
+    """A handle keeps its device slabs, staging buffer and host arrays from request to request (tsgo_hip.hip: Engine::dalloc,
+    release): small after large, large after small, the reference's 150-pose case in between — every answer must be, bit
+    for bit, what a fresh handle gives (nothing of a previous graph may leak into the next: stale table tails, solver
+    history, hierarchy levels that the new graph does not have)."""
+    graphs = [synth.make(600, 8, loop_closures=5, seed=1), synth.make(6000, 12, loop_closures=30, seed=2), util.c1_arrays(),
+              synth.make(2500, 4, loop_closures=0, seed=3), synth.make(6000, 12, loop_closures=30, seed=2), synth.make(40, 3, seed=4)]
+    kept = HipOptimizer(pcg_rel_tol=1e-10)
+    try:
+        for k, g in enumerate(graphs):
+            kept.set_graph(g); r = kept.optimize(4); v = kept.vertices()
+            assert not r["structure_reused"]
+            fresh = HipOptimizer(pcg_rel_tol=1e-10)
+            try:
+                fresh.set_graph(g); rf = fresh.optimize(4); vf = fresh.vertices()
+            finally:
+                fresh.close()
+            np.testing.assert_array_equal(r["chi2"], rf["chi2"], err_msg="graph %d" % k)
+            np.testing.assert_array_equal(r["cg_iters"], rf["cg_iters"], err_msg="graph %d" % k)
+            np.testing.assert_array_equal(v, vf, err_msg="graph %d" % k)
+    finally:
+        kept.close()
+
+
 @pytest.mark.parametrize("precond", ["amg", "jacobi"])
 def test_python_rules_reproduce_the_reference_python_optimizer_on_the_device(precond):
     """SURVEY 8f rank 4 (the `lambdaVal` the C++ declares and never uses, OptimizerCpu.h:70): rules="python" runs the loop of the

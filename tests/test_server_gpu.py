@@ -22,14 +22,13 @@ def _free_port():
     return p
 
 
-@pytest.fixture(scope="module")
-def server():
+def _start(iterations, *extra):
     exe = build.SERVER
     if not os.path.exists(exe):
         pytest.fail("toyslam_amd/graph_optimizer is not built (run __graft_entry__.build())")
     port = _free_port()
     # HOST PORT ITERATIONS PIPELINE SOLVER — the reference's positional CLI (remote/app/main.cpp:12-16)
-    proc = subprocess.Popen([exe, "127.0.0.1", str(port), "50", "gpu", "cuda"], stdout=subprocess.PIPE,
+    proc = subprocess.Popen([exe, "127.0.0.1", str(port), str(iterations), "gpu", "cuda", *extra], stdout=subprocess.PIPE,
                             stderr=subprocess.STDOUT, text=True)
     deadline = time.time() + 60
     while time.time() < deadline:
@@ -40,12 +39,22 @@ def server():
             if proc.poll() is not None:
                 pytest.fail("server exited: " + proc.stdout.read())
             time.sleep(0.2)
-    yield port, proc
+    return port, proc
+
+
+def _stop(proc):
     proc.terminate()
     try:
         proc.wait(timeout=10)
     except subprocess.TimeoutExpired:
         proc.kill()
+
+
+@pytest.fixture(scope="module")
+def server():
+    port, proc = _start(50)
+    yield port, proc
+    _stop(proc)
 
 
 def _roundtrip(sock, request):
@@ -163,3 +172,30 @@ def test_same_structure_then_a_grown_graph_on_one_connection(server):
         v2 = remote.bytes_to_vertices(_roundtrip(s, remote.graph_to_bytes(grown)), grown)
         assert util.max_vertex_diff(v2, ref2["v_pos"], grown.v_type) < 1e-5
     assert proc.poll() is None
+
+
+def test_trailing_arguments_select_the_python_rules_and_the_analytic_odometry_jacobians():
+    """The server's optional trailing arguments (after the reference's five): PRECISION PCG_TOL DEVICE ENGINES RULES ODOM_JACOBIAN.
+    `python:0.5 analytic` must give what the in-process handle gives with rules="python", lr=0.5, odom_jacobian="analytic" —
+    here on a pose graph with loop closures, which the reference's own constants drive into "Error is getting worse"."""
+    from toyslam_amd import synth
+    from toyslam_amd.graph import GraphArrays
+    from toyslam_amd.optimizer import HipOptimizer
+    g = synth.make(400, 6, loop_closures=12, seed=5)
+    keep = g.e_type == 0; pose = g.v_type == 0
+    g = GraphArrays(g.v_id[pose], g.v_type[pose], g.v_pos[pose], g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep], g.fixed).rounded_to_wire()
+    o = HipOptimizer(rules="python", lr=0.5, odom_jacobian="analytic")
+    try:
+        o.set_graph(g); r = o.optimize(8); want = o.vertices()
+    finally:
+        o.close()
+    assert r["chi2"][-1] < 0.2 * r["chi2"][0]                              # this combination converges on such a graph
+    port, proc = _start(8, "64", "1e-10", "0", "1", "python:0.5", "analytic")
+    try:
+        with socket.create_connection(("127.0.0.1", port)) as s:
+            got = remote.bytes_to_vertices(_roundtrip(s, remote.graph_to_bytes(g)), g)
+    finally:
+        _stop(proc)
+    out = proc.stdout.read()
+    assert "lr 0.5" in out and "analytic" in out
+    assert util.max_vertex_diff(got, want, g.v_type) < 1e-4               # the reply is f32 on the wire

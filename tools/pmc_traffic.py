@@ -3,14 +3,15 @@ WRITE_SIZE — they do not fit one pass, MI355X_MICROARCH.md) of `bench.py --ste
 per-dispatch median, gfx950 correction FETCH_SIZE x2 (calibrated on the streaming k_cg_update in round 1).
 Writes a text digest and the JSON bench.py reads for roofline.traffic.
 
-usage: python tools/pmc_traffic.py <out_dir> <tag>      -> <out_dir>/<tag>_pmc_digest.txt, <out_dir>/<tag>_pmc_traffic.json
+usage: python tools/pmc_traffic.py <out_dir> <tag> [workload]      -> <out_dir>/<tag>_pmc_digest.txt, <out_dir>/<tag>_pmc_traffic.json
 Never combines --pmc with a trace domain other than --kernel-trace."""
 import csv, glob, json, os, re, statistics, subprocess, sys
 
 root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
 out_dir, tag = os.path.abspath(sys.argv[1]), sys.argv[2]          # rocprofv3 runs from /tmp: relative paths would land there
 os.makedirs(out_dir, exist_ok=True)
-cmd = ["python3", os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-conv"]
+workload = sys.argv[3] if len(sys.argv) > 3 else "c3_100k"
+cmd = ["python3", os.path.join(root, "bench.py"), "--steps", "2", "--warmup", "1", "--no-cpu", "--no-conv", "--workload", workload]
 os.environ.setdefault("TMPDIR", "/tmp")
 
 
@@ -33,7 +34,7 @@ def run(counter):
 
 
 fetch, write = run("FETCH_SIZE"), run("WRITE_SIZE")
-lines = ["rocprofv3 --pmc passes (separate runs) of: " + " ".join(cmd[:1] + ["bench.py"] + cmd[2:]) + "   [c3_100k, f64]",
+lines = ["rocprofv3 --pmc passes (separate runs) of: " + " ".join(cmd[:1] + ["bench.py"] + cmd[2:]) + "   [%s, f64]" % workload,
          "Per dispatch, KB as reported (median over the dispatches that did work: converged PCG iterations exit early).",
          "gfx950 correction: FETCH_SIZE x2 for coalesced streaming reads, WRITE_SIZE exact.", ""]
 kern = {}
@@ -51,6 +52,6 @@ for plain, ending in (("k_schur_lm", ", 0, 0>"), ("k_schur_pose", ", 0>"), ("k_c
         if k.startswith(plain + "<") and k.endswith(ending):
             kern[plain] = kern[k]
 open(os.path.join(out_dir, tag + "_pmc_digest.txt"), "w").write("\n".join(lines) + "\n")
-json.dump({"workload": "c3_100k", "precision": 64, "source": tag + "_pmc_digest.txt", "kernels": kern},
+json.dump({"workload": workload, "precision": 64, "source": tag + "_pmc_digest.txt", "kernels": kern},
           open(os.path.join(out_dir, tag + "_pmc_traffic.json"), "w"), indent=1)
 print("\n".join(l for l in lines if "k_schur" in l or "k_lin" in l or "k_cg" in l))

@@ -1,0 +1,55 @@
+"""Research soak (GPU): random graphs through the edge-sharded DEVICE path with 2 - 6 ranks on one GPU (in-process all-reduce
+group), against the single-handle run of the same graph.  Shapes: landmark graphs, plain pose graphs, hub landmarks, fixed
+vertices anywhere, both rule sets, both ODOM Jacobians, both preconditioners.  A rank that leaves the collective sequence
+shows as an error after the group's barrier time-out, not as a hang."""
+import sys, time
+import numpy as np
+sys.path.insert(0, "."); sys.path.insert(0, "tests")
+from tests import util
+from tests.test_gpu_sharded_inprocess import _run_sharded, _merge_landmarks
+from toyslam_amd import synth
+from toyslam_amd.graph import GraphArrays
+from toyslam_amd.optimizer import HipOptimizer
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 240.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+t_end = time.time() + budget
+trial = 0; worst = 0.0
+while time.time() < t_end:
+    n = int(rng.integers(60, 12000)); k = int(rng.integers(2, 14)); lc = int(rng.integers(0, max(1, n // 50)))
+    g = synth.make(n, k, loop_closures=lc, seed=int(rng.integers(0, 10 ** 6)))
+    shape = "landmarks"
+    if trial % 6 == 4:
+        keep = g.e_type == 0; pose = g.v_type == 0
+        g = GraphArrays(g.v_id[pose], g.v_type[pose], g.v_pos[pose], g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep], g.fixed)
+        shape = "pose graph"
+    fx = [0] + [int(v) for v in rng.choice(g.v_id, size=int(rng.integers(0, 4)), replace=False)]
+    g.fixed = np.array(fx, np.uint32)
+    world = int(rng.integers(2, 7))
+    precond = "jacobi" if (trial % 5 == 3 and n < 1500) else "amg"
+    oj = "analytic" if trial % 4 == 1 else "constant"
+    rules, lr = ("python", float(rng.choice([0.3, 0.6, 1.0]))) if trial % 3 == 2 else ("cpp", 0.2)
+    kw = dict(pcg_rel_tol=1e-12, preconditioner=precond, odom_jacobian=oj, rules=rules, lr=lr)
+    iters = 6
+    single = HipOptimizer(**kw)
+    try:
+        single.set_graph(g); rs = single.optimize(iters); vs = single.vertices()
+    finally:
+        single.close()
+    outs = _run_sharded(g, world, iters, **kw)
+    v = _merge_landmarks(g, outs)
+    d = util.max_vertex_diff(v, vs, g.v_type)
+    r0 = outs[0][0]
+    same = all(np.array_equal(r["chi2"], r0["chi2"]) and np.array_equal(r["cg_iters"], r0["cg_iters"]) and r["stop"] == r0["stop"] for r, _ in outs)
+    diverging = rs["chi2"][-1] > rs["chi2"][0] or rs["stop"] == "worse"
+    beam = shape == "pose graph" and oj == "analytic"
+    bar = 1e-7 * max(1.0, rs["delta_norm"] / 1e3) * (100 if (diverging or beam) else 1)
+    ok = same and r0["iters"] == rs["iters"] and r0["stop"] == rs["stop"] and np.allclose(r0["chi2"], rs["chi2"], rtol=1e-6 if (diverging or beam) else 1e-9) and d < bar
+    worst = max(worst, d)
+    print("trial %3d %-10s n=%5d k=%2d closures=%3d fixed=%d world=%d %s %s %s: GN %d/%d stop %s/%s cg %s / %s  diff %.2e  %s"
+          % (trial, shape, n, k, lc, len(fx), world, precond, oj, rules, r0["iters"], rs["iters"], r0["stop"], rs["stop"],
+             list(map(int, r0["cg_iters"])), list(map(int, rs["cg_iters"])), d, "ok" if ok else "MISMATCH"), flush=True)
+    if not ok:
+        sys.exit(1)
+    trial += 1
+print("sharded soak: %d graphs, worst vertex difference to the single-handle run %.2e" % (trial, worst))

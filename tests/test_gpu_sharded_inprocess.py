@@ -148,3 +148,21 @@ def test_sharded_stop_rules_and_degenerate_shards(case):
         assert abs(r["delta_norm"] - ref["delta_norm"]) <= 1e-7 * max(1.0, ref["delta_norm"])
     scale = max(1.0, float(np.abs(ref["v_pos"]).max()))
     assert util.max_vertex_diff(_merge_landmarks(g, outs), ref["v_pos"], g.v_type) < 1e-7 * scale
+
+
+def test_shards_whose_own_mean_degrees_straddle_a_lane_threshold():
+    """Two shards with 5.998 and 6.001 LM edges per pose (tests/test_layout_and_twin.py::test_every_shard_chooses_the_same_lanes_per_pose):
+    with per-shard lane choices the ranks' all-reduce buffers had different lengths."""
+    g = synth.make(2077, 12, loop_closures=12, seed=741807)
+    g.fixed = np.array([0, 3754], np.uint32)
+    kw = dict(pcg_rel_tol=1e-12, odom_jacobian="analytic")
+    single = HipOptimizer(**kw)
+    try:
+        single.set_graph(g); rs = single.optimize(6); vs = single.vertices()
+    finally:
+        single.close()
+    outs = _run_sharded(g, 2, 6, **kw)
+    for r, _ in outs:
+        np.testing.assert_allclose(r["chi2"], rs["chi2"], rtol=1e-9)
+        np.testing.assert_array_equal(r["cg_iters"], outs[0][0]["cg_iters"])
+    assert util.max_vertex_diff(_merge_landmarks(g, outs), vs, g.v_type) < 1e-8

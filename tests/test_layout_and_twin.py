@@ -49,6 +49,17 @@ def test_shards_partition_landmarks_edges_and_poses(world):
     assert share.max() / share.mean() < 1.1                   # balanced by edge count
 
 
+def test_every_shard_chooses_the_same_lanes_per_pose():
+    """The ranks all-reduce [3P | one partial per workgroup of the pose table]: the table's shape — lanes per pose — must be the
+    same on every rank.  On this graph the two shards' own mean degrees are 5.998 and 6.001, either side of the 2-lane
+    threshold (found by tests/research/soak_sharded_gpu.py as "ranks disagree on the buffer size")."""
+    g = synth.make(2077, 12, loop_closures=12, seed=741807)
+    for world in (2, 3, 5):
+        infos = [probe(g, rank, world) for rank in range(world)]
+        assert len({i.lanes_per_pose for i in infos}) == 1 and len({i.lanes_per_lm for i in infos}) == 1
+        assert len({i.n_pose for i in infos}) == 1
+
+
 def test_layout_rejects_inconsistent_graphs():
     g = util.tiny_arrays("tiny_a")
     bad = g.copy(); bad.v_id[1] = bad.v_id[0]

@@ -257,8 +257,11 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
     };
     prefix(cP, dP); prefix(cL, dL); prefix(cO, dO);
     int Gp = opt.lanes_per_pose, Gl = opt.lanes_per_lm;
-    if (Gp == 0) Gp = auto_lanes_pose(P ? (double)pr.n_lm_edges / P : 0.0);
-    if (Gl == 0) Gl = auto_lanes_lm(L ? (double)pr.n_lm_edges / L : 0.0);
+    // From quantities every shard knows alike: the ranks all-reduce buffers whose length depends on the pose table's shape
+    // ([3P | one partial per workgroup]), so they must choose the same lanes per pose — a shard's OWN mean degree can fall on
+    // the other side of a threshold than its neighbour's (found by tests/research/soak_sharded_gpu.py: 2 shards, 6.0 edges per pose).
+    if (Gp == 0) Gp = auto_lanes_pose(P ? (double)pr.n_lm_edges_total / pr.world / P : 0.0);
+    if (Gl == 0) Gl = auto_lanes_lm(Lt ? (double)pr.n_lm_edges_total / Lt : 0.0);
     if (!valid_lanes(Gp) || !valid_lanes(Gl)) return "lanes per vertex must be 1, 2, 4 or 8";
 
     shape_table(pr.by_pose, Gp, dP, LM_PLANES, opt.fill_planes);

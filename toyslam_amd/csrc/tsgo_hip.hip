@@ -95,12 +95,21 @@ struct tsgo_local_group {
     std::mutex m; std::condition_variable cv;
     int arrived = 0; long generation = 0;
     std::vector<std::vector<unsigned char>> stage;
-    void barrier() {
+    bool broken = false;                     // a rank gave up waiting: every later barrier fails at once
+    // false: the other ranks did not arrive within kLocalBarrierSeconds (they took a different decision, or one of them
+    // returned with an error) — the caller reports that instead of waiting forever
+    bool barrier() {
         std::unique_lock<std::mutex> l(m);
+        if (broken) return false;
         const long gen = generation;
-        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); }
-        else cv.wait(l, [&] { return generation != gen; });
+        if (++arrived == world) { arrived = 0; ++generation; cv.notify_all(); return true; }
+        if (!cv.wait_for(l, std::chrono::seconds(kLocalBarrierSeconds), [&] { return generation != gen || broken; }) || broken) {
+            broken = true; cv.notify_all();
+            return false;
+        }
+        return true;
     }
+    static constexpr int kLocalBarrierSeconds = 120;
 };
 
 namespace {
@@ -858,14 +867,14 @@ template <typename T> struct Engine : IEngine {
         mine.resize(n * sizeof(U));
         HIP_OK(hipMemcpyAsync(mine.data(), buf, n * sizeof(U), hipMemcpyDeviceToHost, stream));
         HIP_OK(hipStreamSynchronize(stream));
-        G.barrier();                                   // every rank's contribution is staged
+        if (!G.barrier()) return set_error(-12, "in-process all-reduce: the other ranks did not arrive (ranks took different decisions?)");   // every rank's contribution is staged
         std::vector<U> sum(n, U(0));
         for (int r = 0; r < G.world; ++r) {
             if (G.stage[r].size() != n * sizeof(U)) return set_error(-12, "in-process all-reduce: ranks disagree on the buffer size");
             const U* src = (const U*)G.stage[r].data();
             for (size_t k = 0; k < n; ++k) sum[k] += src[k];
         }
-        G.barrier();                                   // nobody restages while another rank still reads
+        if (!G.barrier()) return set_error(-12, "in-process all-reduce: the other ranks did not arrive (ranks took different decisions?)");   // nobody restages while another rank still reads
         HIP_OK(hipMemcpyAsync(buf, sum.data(), n * sizeof(U), hipMemcpyHostToDevice, stream));
         HIP_OK(hipStreamSynchronize(stream));
         return 0;

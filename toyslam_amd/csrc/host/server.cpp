@@ -36,6 +36,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <iostream>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -124,8 +125,16 @@ struct Server {
     // ConnectionHandler.h:18-21): the receive buffer, the decoded graph's arrays, the reply buffer — grow-only, so a
     // client that resends a growing graph does not make the server fault in fresh pages every time — and the engine it
     // used last.
+    // grow-only byte buffer whose new bytes are NOT zeroed (std::vector::resize would write all 57 MB of a 100k-pose message
+    // before recv / the encoder write them again: ~10 ms per direction on a connection's first request)
+    struct Bytes {
+        std::unique_ptr<uint8_t[]> p; size_t cap = 0, n = 0;
+        void resize(size_t want) { if (want > cap) { cap = want + want / 4; p.reset(new uint8_t[cap]); } n = want; }
+        uint8_t* data() { return p.get(); }
+        size_t size() const { return n; }
+    };
     struct Session {
-        std::vector<uint8_t> payload, reply;
+        Bytes payload, reply;
         std::vector<double> v_pos;
         tsgo_wire_graph* w = tsgo_wire_new();
         tsgo_optimizer* last_engine = nullptr;
@@ -141,7 +150,7 @@ struct Server {
         }
         tsgo_graph view; tsgo_wire_view(w, &view);
         std::vector<double>& v_pos = ss.v_pos; v_pos.resize((size_t)view.n_vertices * 3);
-        std::vector<uint8_t>& reply = ss.reply;
+        Bytes& reply = ss.reply;
         tsgo_optimizer*& last_engine = ss.last_engine;
         bool ok = true;
         {
@@ -179,7 +188,7 @@ struct Server {
         std::cout << "\n------ New Connection ------\n";                         // ConnectionHandler.h:10
         int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
         Session ss;
-        std::vector<uint8_t>& payload = ss.payload;
+        Bytes& payload = ss.payload;
         for (;;) {
             int32_t size = 0;                                                    // ConnectionHandlerGraph.h:37-43,57
             if (!read_exact(fd, &size, sizeof(size))) break;

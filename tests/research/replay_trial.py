@@ -1,3 +1,6 @@
+"""Research (GPU): replays trial 33 of `soak_gpu.py 420 31 30000 160000` (the soak's RNG sequence, graphs rebuilt on the host)
+and runs the device at three PCG tolerances: how far apart do two converged runs of the SAME implementation end on that
+graph?  (profiles/r02t_soak_trial33_tolerance_study.txt)"""
 import sys
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np

@@ -363,6 +363,31 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
     }
 }
 
+// out = A z with z stored at row stride `zs` (research, TSGO_CYCLE_EXPLICIT0: the explicit level-0 matrix in place of the
+// implicit Schur product inside the cycle; z is the pose-record array zc, stride kPoseRec).  A plane-major (cycle format).
+template <typename T, int LPR>
+__global__ __launch_bounds__(kBlock) void k_bcsr_apply(int n, const int* __restrict__ ptr, const int* __restrict__ col, const HT<T>* __restrict__ A,
+                                                       const T* __restrict__ z, int zs, T* __restrict__ out, const CgState<T>* __restrict__ st) {
+    if (st->done) return;
+    const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
+    const int i = g < n ? g : n - 1;
+    T s0 = 0, s1 = 0, s2 = 0;
+    const int p0 = ptr[i], p1 = ptr[i + 1];
+    const size_t len = (size_t)(p1 - p0);
+    const HT<T>* base = A + (size_t)p0 * 9;
+    for (int a = p0 + sub; a < p1; a += LPR) {
+        const T* v = z + (size_t)col[a] * zs;
+        const HT<T>* q = base + (a - p0);
+        T b[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) b[m] = q[(size_t)m * len];
+        const T v0 = v[0], v1 = v[1], v2 = v[2];
+        s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
+    }
+    s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
+    if (g < n && sub == 0) { out[(size_t)i * 3] = s0; out[(size_t)i * 3 + 1] = s1; out[(size_t)i * 3 + 2] = s2; }
+}
+
 // rc = P^T v over the rows of R = P^T, and (when dinv_next is given) the next level's pre-smoothing
 // z_next = Dinv_next rc in the same pass.  SUB: v = a - b (level 0: r - S z, never materialised).
 template <typename T, int LPR, int SUB>

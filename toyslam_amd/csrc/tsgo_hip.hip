@@ -235,6 +235,7 @@ template <typename T> struct Engine : IEngine {
         if (const char* e = getenv("TSGO_COARSE_SWEEPS")) { coarse_sweeps = std::max(1, std::min(4, atoi(e))); sweeps_forced = true; }
         if (const char* e = getenv("TSGO_SWEEPS_LIST")) for (const char* q = e; *q;) { sweeps_list.push_back(std::max(1, std::min(4, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
         if (const char* e = getenv("TSGO_CYCLE_F64")) low_cycle = atoi(e) == 0;
+        if (const char* e = getenv("TSGO_CYCLE_EXPLICIT0")) explicit0 = atoi(e) != 0;
         if (const char* e = getenv("TSGO_HIER_MAX_AGE")) hier_max_age = std::max(1, atoi(e));
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
@@ -369,6 +370,7 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&D.Tv, (size_t)D.nnzT * 9)) return rc;
         if (int rc = dalloc(&D.Ppm, (size_t)D.nnzP * 9)) return rc;
         if (int rc = dalloc(&D.Rpm, (size_t)D.nnzP * 9)) return rc;
+        if (l == 0 && explicit0) { if (int rc = dalloc(&D.Apm, (size_t)D.nnzA * 9)) return rc; }
         if (l > 0) {
             if (int rc = dalloc(&D.Apm, (size_t)D.nnzA * 9)) return rc;
             if (int rc = dalloc(&D.r, (size_t)D.n * 3)) return rc;
@@ -665,6 +667,7 @@ template <typename T> struct Engine : IEngine {
                            sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A, pr.rank == 0 ? 1 : 0,
                            to.idx, oj() ? 1 : 0);
         if (int rc = allreduce_h(L0.A, (size_t)L0.nnzA * 9)) return rc;
+        if (explicit0) hipLaunchKernelGGL((k_to_planes<T>), dim3(grid_for(L0.n, 8)), dim3(kBlock), 0, stream, L0.n, (const int*)L0.A_ptr, (const H*)L0.A, L0.Apm);
         for (size_t l = 0; l < lv.size(); ++l) {
             DevLevel<T>& L = lv[l];
             H* Anext = l + 1 < lv.size() ? lv[l + 1].A : A_last;
@@ -769,10 +772,25 @@ template <typename T> struct Engine : IEngine {
     // zc[.][0..2] = V(1,1)-cycle(r).  On entry zc already holds the level-0 pre-smoothing Minv r
     // (written by pose_finalize / k_cg_step).  Level l >= 1 keeps r, z (pre-smoothed by the restriction
     // above it), res and the post-smoothed result z2.
+    // research (TSGO_CYCLE_EXPLICIT0=1): the two products inside the cycle read the EXPLICIT level-0 matrix of the hierarchy
+    // (lagged with it, hub landmarks truncated, f32) instead of the implicit Schur passes — no all-reduce in a sharded run
+    bool explicit0 = false;
+    int launch_cycle_product(int slot) {
+        if (!explicit0) return launch_matvec(slot, false, low_cycle);
+        DevLevel<T>& L = lv[0];
+        switch (lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n)) {
+            case 4: hipLaunchKernelGGL((k_bcsr_apply<T, 4>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
+            case 8: hipLaunchKernelGGL((k_bcsr_apply<T, 8>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
+            case 16: hipLaunchKernelGGL((k_bcsr_apply<T, 16>), dim3(grid_for(L.n, 16)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
+            case 32: hipLaunchKernelGGL((k_bcsr_apply<T, 32>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
+            default: hipLaunchKernelGGL((k_bcsr_apply<T, 64>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
+        }
+        return 0;
+    }
     int launch_vcycle(int slot) {
         const CgState<T>* s = st[slot];
         const size_t nl = lv.size();              // explicit levels 0 .. nl-1, dense level below
-        if (int rc = launch_matvec(slot, false, low_cycle)) return rc;
+        if (int rc = launch_cycle_product(slot)) return rc;
         {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
@@ -827,7 +845,7 @@ template <typename T> struct Engine : IEngine {
             // nu post-sweeps after nu-1 pre-swaps: the result sits in L.z2 for every nu (odd+odd / even+even swaps)
         }
         launch_prolong(lv[0], nl > 1 ? (const T*)lv[1].z2 : (const T*)z_last, zc, kPoseRec, s);
-        if (int rc = launch_matvec(slot, false, low_cycle)) return rc;
+        if (int rc = launch_cycle_product(slot)) return rc;
         hipLaunchKernelGGL((k_smooth0<T, 1>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, (const T*)omega_dev, s);
         return 0;
     }

@@ -13,8 +13,8 @@ N = 1: BASELINE.json config 3 (100k poses / 1M LM edges on one MI355X).
 N > 1 (default): BASELINE.json config 4 — the SAME one graph, edge-sharded across the N ranks ("scaling": "strong"):
 every rank owns a contiguous landmark range with all its LM edges plus the ODOM rows / gauge terms of a contiguous pose
 range; pose state, PCG vectors and the multigrid hierarchy are replicated.  RCCL all-reduces: the pose partials once per
-GN iteration, every Schur product (three per multigrid-preconditioned PCG iteration), the level-0 blocks once per
-hierarchy build.  DESIGN.md section 5 gives the expected 1 -> 8 curve and why this size is latency-bound.
+GN iteration, the PCG's Schur product once per iteration (the two products inside the multigrid cycle read the replicated
+explicit level-0 matrix; --implicit-cycle shards and all-reduces them too), the level-0 blocks once per hierarchy build.  DESIGN.md section 5 gives the expected 1 -> 8 curve and why this size is latency-bound.
 `--request-parallel` instead gives every rank its OWN graph of the named configuration (what a multi-GPU
 graph_optimizer does with independent connections; no data-path collective, "scaling": "weak").
 
@@ -129,6 +129,12 @@ def main():
             dist.barrier()                           # the communicator (and its banner) is created lazily: now
 
     shard = world > 1 and not ARGS.request_parallel
+    # Sharded runs take the two products INSIDE the multigrid cycle from the replicated explicit level-0 matrix (engine switch
+    # TSGO_CYCLE_EXPLICIT0): one all-reduce per PCG iteration instead of three for 6 % more iterations — ahead as soon as an
+    # all-reduce costs more than 19 us (profiles/r02e_explicit_level0_in_cycle.txt).  --implicit-cycle keeps the single-device form.
+    explicit_cycle = shard and not ARGS.implicit_cycle
+    if explicit_cycle:
+        os.environ.setdefault("TSGO_CYCLE_EXPLICIT0", "1")
     g = synth.make_config(ARGS.workload, seed=0 if shard else rank)
     n_edges = len(g.e_type)
     opt = HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol,
@@ -183,7 +189,8 @@ def main():
         shares = {}
         for which in (0, 1, 2, 3, 4):
             us, nbytes = opt.time_kernel(which, reps=200)
-            launches = {0: 3.0 if amg else 1.0, 1: 3.0 if amg else 1.0, 2: 0.0 if amg else 1.0}     # per PCG iteration
+            n_prod = 3.0 if (amg and not explicit_cycle) else 1.0                                   # implicit Schur products per PCG iteration
+            launches = {0: n_prod, 1: n_prod, 2: 0.0 if amg else 1.0}
             per_step = us * (n_cg * launches[which] if which < 3 else 1.0)
             shares[KERNELS[which]] = {"us_per_launch": us, "algorithmic_bytes_per_launch": nbytes, "launches_per_step": (n_cg * launches[which] if which < 3 else 1.0),
                                       "us_per_step": per_step}
@@ -221,7 +228,7 @@ def main():
                                    % (ARGS.workload, g.n_poses, g.n_landmarks, Eo, El),
                        "solver": "implicit-Schur PCG (Chronopoulos-Gear), %s, rel tol %g"
                                  % ("smoothed-aggregation multigrid V(1,1) preconditioner" if amg else "block-Jacobi on the Schur diagonal", ARGS.pcg_tol),
-                       "parallelism": ("BASELINE config 4: one graph edge-sharded x%d (landmark ranges), replicated multigrid hierarchy, RCCL all-reduce per Schur product" % world) if shard else
+                       "parallelism": ("BASELINE config 4: one graph edge-sharded x%d (landmark ranges), replicated multigrid hierarchy, %s" % (world, "in-cycle products on the replicated explicit level-0 matrix: one RCCL all-reduce per PCG iteration" if explicit_cycle else "RCCL all-reduce per Schur product (three per PCG iteration)")) if shard else
                                       ("request-parallel: %d independent graphs, one per GPU, no collective" % world if world > 1 else
                                        ("single GPU, collective code path forced (one-rank RCCL communicator)" if ARGS.force_collective else "single GPU")),
                        "hipgraph": (not ARGS.no_graphs) and not shard and not ARGS.force_collective},
@@ -271,6 +278,8 @@ if __name__ == "__main__":
     ap.add_argument("--request-parallel", dest="request_parallel", action="store_true",
                     help="N > 1: every rank optimises its own graph (weak scaling) instead of sharding ONE graph (BASELINE config 4)")
     ap.add_argument("--shard", action="store_true", help="accepted for compatibility: sharding is the default for N > 1")
+    ap.add_argument("--implicit-cycle", dest="implicit_cycle", action="store_true",
+                    help="N > 1: keep the implicit (sharded, all-reduced) Schur products inside the multigrid cycle: three all-reduces per PCG iteration")
     ap.add_argument("--force-collective", dest="force_collective", action="store_true",
                     help="N = 1: give the engine a one-rank RCCL communicator so that it takes the sharded code path (eager launches, all-reduce calls)")
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true")

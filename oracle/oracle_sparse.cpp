@@ -153,12 +153,19 @@ struct Twin {
             if (!amg.levels.empty()) for (int k = 0; k < 3; ++k) z[3 * (size_t)i + k] *= w0;
         }
         if (amg.levels.empty()) return;
-        schur_lm(z); schur_pose(z, s0); allreduce(s0.data(), (int64_t)s0.size());
+        // TSGO_CYCLE_EXPLICIT0=1 (the engine's switch of the same name, tsgo_hip.hip: launch_cycle_product): inside the cycle the
+        // product with the replicated EXPLICIT level-0 matrix — as old as the hierarchy — and no all-reduce
+        static const bool explicit0 = getenv("TSGO_CYCLE_EXPLICIT0") && atoi(getenv("TSGO_CYCLE_EXPLICIT0")) != 0;
+        auto cycle_product = [&] {
+            if (explicit0) { amgtwin::Hierarchy::spmv(amg.levels[0].A, hier.A[0], z, s0); return; }
+            schur_lm(z); schur_pose(z, s0); allreduce(s0.data(), (int64_t)s0.size());
+        };
+        cycle_product();
         for (size_t k = 0; k < s0.size(); ++k) res0[k] = r[k] - s0[k];
         hier.restrict_to(0, res0, hier.r[1]);
         hier.cycle(1);
         hier.prolong_add(0, hier.z[1], z);
-        schur_lm(z); schur_pose(z, s0); allreduce(s0.data(), (int64_t)s0.size());
+        cycle_product();
         for (int i = 0; i < P; ++i) {
             double d0, d1, d2;
             tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i] - s0[3 * (size_t)i], r[3 * (size_t)i + 1] - s0[3 * (size_t)i + 1], r[3 * (size_t)i + 2] - s0[3 * (size_t)i + 2], d0, d1, d2);

@@ -166,3 +166,31 @@ def test_shards_whose_own_mean_degrees_straddle_a_lane_threshold():
         np.testing.assert_allclose(r["chi2"], rs["chi2"], rtol=1e-9)
         np.testing.assert_array_equal(r["cg_iters"], outs[0][0]["cg_iters"])
     assert util.max_vertex_diff(_merge_landmarks(g, outs), vs, g.v_type) < 1e-8
+
+
+def test_one_all_reduce_per_iteration_variant_on_the_device(monkeypatch):
+    """What `bench.py --gpus N` runs (TSGO_CYCLE_EXPLICIT0=1, read by every handle when it is created): in-cycle products on the
+    replicated explicit level-0 matrix.  Three ranks against a single handle with the switch, and against the default form."""
+    g = synth.make(6000, 10, loop_closures=40, seed=13)
+    g.fixed = np.array([0, int(g.v_id[4000]), int(g.v_id[-5])], np.uint32)
+    plain = HipOptimizer(pcg_rel_tol=1e-12)
+    try:
+        plain.set_graph(g); rp = plain.optimize(5); vp = plain.vertices()
+    finally:
+        plain.close()
+    monkeypatch.setenv("TSGO_CYCLE_EXPLICIT0", "1")
+    single = HipOptimizer(pcg_rel_tol=1e-12)
+    try:
+        single.set_graph(g); rs = single.optimize(5); vs = single.vertices()
+    finally:
+        single.close()
+    assert not np.array_equal(rs["cg_iters"], rp["cg_iters"])                    # the switch did change the preconditioner ...
+    np.testing.assert_allclose(rs["chi2"], rp["chi2"], rtol=1e-10)               # ... and not the answer
+    assert util.max_vertex_diff(vs, vp, g.v_type) < 1e-8
+    outs = _run_sharded(g, 3, 5, pcg_rel_tol=1e-12)
+    for r, _ in outs:
+        np.testing.assert_allclose(r["chi2"], rs["chi2"], rtol=1e-10)
+        np.testing.assert_array_equal(r["chi2"], outs[0][0]["chi2"])
+        np.testing.assert_array_equal(r["cg_iters"], outs[0][0]["cg_iters"])
+        assert r["fallbacks"] == 0 and np.all(np.abs(r["cg_iters"] - rs["cg_iters"]) <= 3), (r["cg_iters"], rs["cg_iters"])
+    assert util.max_vertex_diff(_merge_landmarks(g, outs), vs, g.v_type) < 1e-8

@@ -21,8 +21,10 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, n_poses, precond, rules):
+def _worker(rank, world, port, out_dir, n_poses, precond, rules, explicit_cycle=False):
     sys.path.insert(0, ROOT)
+    if explicit_cycle:                 # read once per process by the twin (and by the engine): set before the first solve
+        os.environ["TSGO_CYCLE_EXPLICIT0"] = "1"
     torch.set_num_threads(2)      # also sizes the twin's OpenMP loops (same libgomp)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -69,3 +71,32 @@ def test_sharded_run_across_processes_matches_single_process(tmp_path, world, pr
     for o in outs[1:]:
         np.testing.assert_array_equal(outs[0]["chi2"], o["chi2"])      # ranks agree bit for bit
         np.testing.assert_array_equal(outs[0]["cg"], o["cg"])          # ... and take the same decisions (or RCCL would hang)
+
+
+def test_one_all_reduce_per_iteration_variant_across_processes(tmp_path):
+    """What `bench.py --gpus N` runs (TSGO_CYCLE_EXPLICIT0=1): the two products inside the multigrid cycle read the replicated
+    explicit level-0 matrix, so only the PCG's own product is all-reduced.  Two processes against one, both with the switch
+    (each in a fresh process: the switch is read once), and against the default form's answer; the hook is called far less."""
+    one = tmp_path / "one"; two = tmp_path / "two"; plain = tmp_path / "plain"
+    for d in (one, two, plain):
+        d.mkdir()
+    mp.spawn(_worker, args=(1, _free_port(), str(one), 1500, "amg", "cpp", True), nprocs=1, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(two), 1500, "amg", "cpp", True), nprocs=2, join=True)
+    mp.spawn(_worker, args=(2, _free_port(), str(plain), 1500, "amg", "cpp", False), nprocs=2, join=True)
+    ref = np.load(os.path.join(str(one), "rank0.npz"))
+    outs = [np.load(os.path.join(str(two), "rank%d.npz" % r)) for r in range(2)]
+    base = np.load(os.path.join(str(plain), "rank0.npz"))
+    from toyslam_amd import synth
+    from tests import util
+    g = synth.make(1500, 10, loop_closures=30, seed=11)
+    for o in outs:
+        np.testing.assert_allclose(o["chi2"], ref["chi2"], rtol=1e-11)
+        assert util.max_vertex_diff(o["v"], ref["v"], g.v_type) < 1e-9
+        assert np.all(np.abs(o["cg"] - ref["cg"]) <= 2), (o["cg"], ref["cg"])
+        np.testing.assert_allclose(o["chi2"], base["chi2"], rtol=1e-9)           # the same answer as the default form
+        assert o["cg"].max() < 80
+    np.testing.assert_array_equal(outs[0]["chi2"], outs[1]["chi2"])
+    np.testing.assert_array_equal(outs[0]["cg"], outs[1]["cg"])
+    # per PCG iteration one all-reduce instead of three
+    per_it = float(outs[0]["calls"]) / float(outs[0]["cg"].sum()); per_it_plain = float(base["calls"]) / float(base["cg"].sum())
+    assert per_it < 1.6 and per_it_plain > 2.8, (per_it, per_it_plain)

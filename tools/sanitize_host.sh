@@ -18,4 +18,7 @@ src="host/problem.cpp host/amg.cpp host/codec.cpp host/synth.cpp host/host_api.c
   echo "fuzz: 3000 truncated / bit-flipped wire requests through tsgo_wire_decode + encode_response"
   LD_PRELOAD="$(gcc -print-file-name=libasan.so) $(gcc -print-file-name=libubsan.so)" ASAN_OPTIONS=detect_leaks=0:abort_on_error=1 \
     TSGO_HOST_SO=$so python tools/fuzz_codec.py 3000 2>&1 | tail -5
+  echo "ThreadSanitizer: layout (parallel slot fill) + multigrid patterns (parallel products, helper thread for the next level's aggregates), whole graph and one shard of two, 6 threads"
+  (cd toyslam_amd/csrc && g++ -O1 -g -std=c++17 -pthread -fsanitize=thread -o /tmp/tsgo_tsan_driver ../../tools/tsan_driver.cpp $src)
+  TSGO_HOST_THREADS=6 /tmp/tsgo_tsan_driver 2>&1 | tail -12
 } | tee "$out"

@@ -142,7 +142,7 @@ def optimize(g, iterations, mode="cpp", solver="chol", lr=0.2, precision="f64"):
     out = np.zeros_like(g.v_pos); chi2 = np.zeros(max(iterations, 1))
     ir = np.zeros(1, np.int32); sr = np.zeros(1, np.int32); dn = np.zeros(1)
     rc = getattr(lib(), "oracle_optimize_" + _sfx(precision))(
-        *g.args(), out, iterations, {"cpp": 0, "python": 1}[mode], {"qr": 0, "chol": 1}[solver], lr, chi2, ir, sr, dn)
+        *g.args(), out, iterations, {"cpp": 0, "python": 1, "cpp_on_python_linearisation": 2}[mode], {"qr": 0, "chol": 1}[solver], lr, chi2, ir, sr, dn)
     if rc:
         raise RuntimeError("oracle_optimize rc=%d" % rc)
     return dict(v_pos=out, chi2=chi2[:ir[0]].copy(), iters=int(ir[0]), stop=STOP[int(sr[0])], delta_norm=float(dn[0]))

@@ -69,6 +69,45 @@ def test_response_form_is_the_asymmetric_one():
     assert (t, rows, cols) == (1, 2, 1)
 
 
+@pytest.mark.parametrize("name", ["c1", "tiny_a", "tiny_b", "tiny_c"])
+def test_reply_as_read_by_the_reference(name):
+    """The reply form pinned by the REFERENCE's reader: tests/golden/make_golden_r3.py handed the reply this codec encodes to
+    python/remote/bytes_to_graph.py:49-108 and stored what it returned.  Here: the codec still writes those very bytes (SHA-1),
+    and this repo's reader (remote.bytes_to_arrays, remote.bytes_to_vertices) reads them as the reference did."""
+    import hashlib
+    z = util.load(name + "_reply_ref.npz")
+    req = golden_request() if name == "c1" else util.load(name + ".npz")["request"].tobytes()
+    rep = remote.encode_response(req[4:], z["reply_vertices_in"])
+    assert hashlib.sha1(rep).digest() == z["reply_sha1"].tobytes()
+    out = remote.bytes_to_arrays(rep[4:])
+    np.testing.assert_array_equal(out.v_id, z["v_id"])          # the reference's dict keeps the reply's vertex order
+    np.testing.assert_array_equal(out.v_type, z["v_type"])
+    pose = z["v_type"] == 0
+    vm = z["v_mat"].astype(np.float64)
+    # poses: the reader rebuilds [[c, -s, x], [s, c, y], [0, 0, 1]] in float32 from (x, y, theta)
+    np.testing.assert_array_equal(out.v_pos[pose, 0], vm[pose, 2]); np.testing.assert_array_equal(out.v_pos[pose, 1], vm[pose, 5])
+    th = out.v_pos[pose, 2]
+    np.testing.assert_allclose(np.cos(th), vm[pose, 0], atol=1e-7); np.testing.assert_allclose(np.sin(th), vm[pose, 3], atol=1e-7)
+    np.testing.assert_allclose(-np.sin(th), vm[pose, 1], atol=1e-7); np.testing.assert_allclose(np.cos(th), vm[pose, 4], atol=1e-7)
+    assert np.all(vm[pose, 6:] == [0, 0, 1])
+    np.testing.assert_array_equal(out.v_pos[~pose, :2], vm[~pose, :2])
+    # what went in comes out (f32-exact inputs)
+    np.testing.assert_array_equal(out.v_pos, z["reply_vertices_in"])
+    np.testing.assert_array_equal(out.e_type, z["e_type"]); np.testing.assert_array_equal(out.e_ids, z["e_ids"])
+    odom = z["e_type"] == 0
+    assert np.all(z["e_meas_shape"][odom] == [3, 3]) and np.all(z["e_meas_shape"][~odom] == [2, 1])      # SerializeGraphFuncCpu.h:56-58
+    np.testing.assert_array_equal(out.e_meas, z["e_meas"].astype(np.float64))
+    # information: the reader builds a k x k diagonal matrix from (0, k) + k floats
+    assert np.all(z["e_inf_shape"][odom] == [3, 3]) and np.all(z["e_inf_shape"][~odom] == [2, 2])
+    inf = z["e_inf"].astype(np.float64)
+    np.testing.assert_array_equal(out.e_inf[odom], inf[odom][:, [0, 4, 8]])
+    np.testing.assert_array_equal(out.e_inf[~odom][:, :2], inf[~odom][:, [0, 3]])
+    assert np.all(inf[odom][:, [1, 2, 3, 5, 6, 7]] == 0) and np.all(inf[~odom][:, [1, 2]] == 0)
+    np.testing.assert_array_equal(np.sort(np.asarray(out.fixed)), z["fixed"])
+    like = remote.decode_request(req[4:])
+    np.testing.assert_array_equal(remote.bytes_to_vertices(rep[4:], like), z["reply_vertices_in"])
+
+
 def test_request_form_cannot_be_read_as_reply_and_vice_versa():
     req = golden_request()
     with pytest.raises(Exception):

@@ -36,8 +36,24 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-PMC_TRAFFIC = os.path.join("profiles", "r02_pmc_traffic.json")   # rocprofv3 --pmc digest of this same command (tools/pmc_traffic.py)
+PMC_TRAFFIC = os.path.join("profiles", "r03_pmc_traffic.json")   # rocprofv3 --pmc digest of this same command (tools/pmc_traffic.py)
+ROCPROF_STATS = os.path.join("profiles", "r03_rocprofv3_kernel_stats.csv")   # rocprofv3 --kernel-trace --stats of this same command
 KERNELS = {0: "k_schur_lm", 1: "k_schur_pose", 2: "k_cg_update", 3: "k_lin_lm", 4: "k_lin_pose"}
+
+
+def rocprof_average_us(symbol):
+    """Average duration of `symbol` (kernel name without arguments, as rocprofv3 prints it) in the COMMITTED --stats CSV."""
+    import csv
+    try:
+        for row in csv.DictReader(open(os.path.join(ROOT, ROCPROF_STATS))):
+            name = row["Name"]
+            name = name[len("void "):] if name.startswith("void ") else name
+            name = name[len("tsgo::"):] if name.startswith("tsgo::") else name
+            if name.split("(")[0] == symbol:
+                return float(row["AverageNs"]) / 1e3
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def pmc_traffic(kernel, workload, precision):
@@ -47,7 +63,8 @@ def pmc_traffic(kernel, workload, precision):
         d = json.load(open(os.path.join(ROOT, PMC_TRAFFIC)))
         if d.get("workload") != workload or d.get("precision") != precision:
             return None
-        return d["kernels"].get(kernel, {}).get("hbm_bytes_corrected")
+        k = d["kernels"].get(kernel, {})
+        return k.get("hbm_bytes_mean", k.get("hbm_bytes_corrected"))
     except (OSError, ValueError, KeyError):
         return None
 
@@ -129,18 +146,16 @@ def main():
             dist.barrier()                           # the communicator (and its banner) is created lazily: now
 
     shard = world > 1 and not ARGS.request_parallel
-    # Sharded runs take the two products INSIDE the multigrid cycle from the replicated explicit level-0 matrix (engine switch
-    # TSGO_CYCLE_EXPLICIT0): one all-reduce per PCG iteration instead of three for 6 % more iterations — ahead as soon as an
+    # Sharded runs take the two products INSIDE the multigrid cycle from the replicated explicit level-0 matrix
+    # (tsgo_config.cycle_level0 = 1): one all-reduce per PCG iteration instead of three for 6 % more iterations — ahead as soon as an
     # all-reduce costs more than 19 us (profiles/r02e_explicit_level0_in_cycle.txt).  --implicit-cycle keeps the single-device form.
-    explicit_cycle = shard and not ARGS.implicit_cycle
-    if explicit_cycle:
-        os.environ.setdefault("TSGO_CYCLE_EXPLICIT0", "1")
+    explicit_cycle = (shard and not ARGS.implicit_cycle) or ARGS.explicit_cycle
     g = synth.make_config(ARGS.workload, seed=0 if shard else rank)
     n_edges = len(g.e_type)
     opt = HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol,
                        rank=rank if shard else 0, world=world if shard else 1,
                        use_graphs=not ARGS.no_graphs, lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
-                       preconditioner=ARGS.precond)
+                       preconditioner=ARGS.precond, cycle_level0="explicit" if explicit_cycle else "implicit", cycle_storage=ARGS.cycle_storage)
     if ARGS.force_collective and world == 1:          # research: the sharded code path (eager launches + RCCL calls) with a one-rank communicator
         with stdout_to_stderr():
             opt.comm_init(opt.comm_unique_id())
@@ -186,19 +201,38 @@ def main():
     if rank == 0 or shard:
         n_cg = float(np.mean(timed_cg)) if timed_cg else 0.0
         amg = ARGS.precond == "amg"
+        # In situ: one PCG iteration launched eagerly with a hipEvent before every kernel, on the engine's stream, averaged over 20
+        # iterations (tsgo_profile_iteration) — every kernel in the cache state the solve leaves it in.  An event between two
+        # kernels costs a little itself: the sum of the marks against the same iteration timed without them gives that cost per
+        # launch, which is taken off every entry ("us_in_situ"; "us_in_situ_raw" is the interval as recorded).
+        prof = opt.profile_iteration(reps=20)
+        us_pcg = opt.time_kernel(5, reps=20)[0]
+        overhead = max(0.0, (sum(e["us"] for e in prof) - us_pcg) / max(1, len(prof)))
         shares = {}
+        for e in prof:
+            k = shares.setdefault(e["name"], {"launches_per_iteration": 0, "us_raw": 0.0, "bytes": 0.0, "where": []})
+            k["launches_per_iteration"] += 1; k["us_raw"] += e["us"]; k["bytes"] += e["bytes"]; k["where"].append(e["where"])
+        for name, k in shares.items():
+            n = k["launches_per_iteration"]
+            k["us_in_situ_raw"] = k.pop("us_raw") / n
+            k["us_in_situ"] = max(k["us_in_situ_raw"] - overhead, 1e-3)
+            k["algorithmic_bytes_per_launch"] = k.pop("bytes") / n
+            k["launches_per_step"] = n_cg * n
+            k["us_per_step"] = k["us_in_situ"] * n_cg * n
+            k["us_rocprof_stats"] = rocprof_average_us(name)
+            k["achieved_GBps"] = k["algorithmic_bytes_per_launch"] / (k["us_in_situ"] * 1e-6) / 1e9
+            k["frac_of_hbm_peak"] = k["achieved_GBps"] / HBM_PEAK_GBS
+        # back-to-back figures of the table kernels (200 launches of one kernel in a row: warm L2 / MALL), for comparison
+        tname = "double" if ARGS.precision == 64 else "float"
         for which in (0, 1, 2, 3, 4):
             us, nbytes = opt.time_kernel(which, reps=200)
-            n_prod = 3.0 if (amg and not explicit_cycle) else 1.0                                   # implicit Schur products per PCG iteration
-            launches = {0: n_prod, 1: n_prod, 2: 0.0 if amg else 1.0}
-            per_step = us * (n_cg * launches[which] if which < 3 else 1.0)
-            shares[KERNELS[which]] = {"us_per_launch": us, "algorithmic_bytes_per_launch": nbytes, "launches_per_step": (n_cg * launches[which] if which < 3 else 1.0),
-                                      "us_per_step": per_step}
-        if amg:                 # the coarse levels of the V-cycle: one smoothing sweep per level, and how many the cycle runs
-            for lvl, (us, nbytes, launches) in enumerate(opt.level_sweep_times(reps=100), start=1):
-                shares["k_bcsr_residual@level%d" % lvl] = {"us_per_launch": us, "algorithmic_bytes_per_launch": nbytes, "launches_per_step": n_cg * launches,
-                                                             "us_per_step": us * n_cg * launches}
-        us_pcg = opt.time_kernel(5, reps=20)[0]
+            hit = [n for n in shares if n.startswith(KERNELS[which] + "<" + tname) and (which >= 2 or ", 0, 0>" in n or n.endswith(", 0>"))]
+            if hit:
+                shares[hit[0]]["us_back_to_back"] = us
+            elif which >= 3:      # the two linearisation kernels run once per step, outside the PCG iteration
+                shares[KERNELS[which]] = {"launches_per_iteration": 0, "us_back_to_back": us, "us_in_situ": us, "algorithmic_bytes_per_launch": nbytes,
+                                          "launches_per_step": 1.0, "us_per_step": us, "us_rocprof_stats": None, "achieved_GBps": nbytes / (us * 1e-6) / 1e9,
+                                          "frac_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "where": ["linearisation (timed back to back)"]}
         us_setup = opt.time_kernel(6, reps=5)[0] if amg else None
         conv = None
         if not ARGS.no_conv:
@@ -206,12 +240,28 @@ def main():
             # |chi2_k - chi2_{k-1}| < 1e-3 fires (OptimizerCpu.h:167-171), capped at 50; a fresh run, outside the timed region
             opt.set_graph(g)
             rc = opt.optimize(50)
-            conv = {"iterations": int(rc["iters"]), "stop": rc["stop"], "cap": 50, "chi2_first": float(rc["chi2"][0]),
-                    "chi2_last": float(rc["chi2"][-1]), "pcg_iters_total": int(rc["cg_total"]),
-                    "seconds": rc["ms_total"] / 1e3, "pcg_fallbacks": int(rc["fallbacks"])}
+            def conv_of(rc):
+                return {"iterations": int(rc["iters"]), "stop": rc["stop"], "cap": 50, "chi2_first": float(rc["chi2"][0]),
+                        "chi2_last": float(rc["chi2"][-1]), "pcg_iters_total": int(rc["cg_total"]),
+                        "seconds": rc["ms_total"] / 1e3, "pcg_fallbacks": int(rc["fallbacks"])}
+            conv = conv_of(rc)
+            if conv["stop"] == "cap":
+                conv["note"] = "the plateau rule |chi2_k - chi2_(k-1)| < 1e-3 does not fire within the cap at this size (chi2 is still falling by more than 1e-3 per 0.2-damped step): the figure is the cap; see other_configs for the configurations where it does fire"
+            if world == 1 and ARGS.workload == "c3_100k":
+                # ... and where the rule does fire: config 1 (the reference's own graph; plateau at iteration 41 under cpu/eigen too,
+                # tests/golden/c1_cpprules_ref.npz) and config 2
+                from toyslam_amd.graph import GraphArrays
+                other = {}
+                z = np.load(os.path.join(ROOT, "tests", "golden", "c1_graph.npz"))
+                c1 = GraphArrays(z["v_id"], z["v_type"], z["v_pos"], z["e_type"], z["e_ids"], z["e_meas"], z["e_inf"], z["fixed"]).rounded_to_wire()
+                for name, gg in (("c1_reference_sim", c1), ("c2_10k", synth.make_config("c2_10k"))):
+                    opt.set_graph(gg)
+                    other[name] = conv_of(opt.optimize(50))
+                conv["other_configs"] = other
+                opt.set_graph(g)
     if rank == 0:
         dom = max(shares, key=lambda k: shares[k]["us_per_step"])
-        us, nbytes = shares[dom]["us_per_launch"], shares[dom]["algorithmic_bytes_per_launch"]
+        us, nbytes = shares[dom]["us_in_situ"], shares[dom]["algorithmic_bytes_per_launch"]
         achieved = nbytes / (us * 1e-6) / 1e9
         s = 8 if ARGS.precision == 64 else 4
         Eo, El = int((g.e_type == 0).sum()), int((g.e_type == 1).sum())
@@ -241,8 +291,12 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_source": (PMC_TRAFFIC + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE passes of this same command, committed; NOT measured in this run)") if traffic is not None else None,
                          "us_per_launch": us, "algorithmic_bytes_per_launch": nbytes,
-                         "kernel_chosen_by": "largest us_per_launch x launches_per_step among the kernels below (hipEvent, back-to-back launches on the engine's stream)",
+                         "us_per_launch_rocprof_stats": shares[dom].get("us_rocprof_stats"), "rocprof_stats_source": ROCPROF_STATS,
+                         "kernel_chosen_by": "largest in-situ time per step, grouped by kernel symbol as rocprofv3 groups them (all levels / call sites of one instantiation together)",
+                         "timing": "hipEvent before every launch of 20 eagerly launched PCG iterations on the engine's stream (tsgo_profile_iteration), minus the per-launch cost of the events themselves (%.2f us: sum of the marks vs the same iteration without them); algorithmic bytes = average over the symbol's launches in one iteration" % overhead,
+                         "event_overhead_us_per_launch": overhead,
                          "kernels": shares,
+                         "iteration_in_launch_order": [{"kernel": e["name"], "where": e["where"], "us_in_situ_raw": e["us"], "algorithmic_bytes": e["bytes"]} for e in prof],
                          # SURVEY 8d's own byte model, with the measured PCG iteration count: what a perfect implementation of the
                          # reference's sparse-equivalent algorithm would have to move, against what this run took
                          "step": {"algorithmic_bytes": b_gn, "B_lin": b_lin, "B_cg": b_cg, "B_upd": b_upd, "N_cg": n_cg, "ms": ms_step,
@@ -280,6 +334,10 @@ if __name__ == "__main__":
     ap.add_argument("--shard", action="store_true", help="accepted for compatibility: sharding is the default for N > 1")
     ap.add_argument("--implicit-cycle", dest="implicit_cycle", action="store_true",
                     help="N > 1: keep the implicit (sharded, all-reduced) Schur products inside the multigrid cycle: three all-reduces per PCG iteration")
+    ap.add_argument("--explicit-cycle", dest="explicit_cycle", action="store_true",
+                    help="N = 1: tsgo_config.cycle_level0 = 1 (what N > 1 runs by default)")
+    ap.add_argument("--cycle-storage", dest="cycle_storage", type=int, default=16, choices=[16, 32],
+                    help="tsgo_config.cycle_storage: the V-cycle's copies of the hierarchy as packed half floats (default) or f32")
     ap.add_argument("--force-collective", dest="force_collective", action="store_true",
                     help="N = 1: give the engine a one-rank RCCL communicator so that it takes the sharded code path (eager launches, all-reduce calls)")
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true")

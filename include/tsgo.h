@@ -52,15 +52,18 @@ typedef struct tsgo_optimizer tsgo_optimizer;
 typedef struct tsgo_config {
     int32_t device;          /* HIP device ordinal */
     int32_t precision;       /* 64 (default, parity mode) or 32 */
-    double pcg_rel_tol;      /* stop PCG when sqrt(r^T M^-1 r) <= tol * sqrt(b^T M^-1 b); default 1e-10 */
+    double pcg_rel_tol;      /* stop PCG when sqrt(r^T D^-1 r) <= tol * sqrt(b^T D^-1 b), D = the 3x3 block diagonal of the reduced pose
+                                system (both preconditioners; the residual norm block-Jacobi PCG measures); default 1e-10 */
     int32_t pcg_max_iters;   /* cap per Gauss-Newton iteration; default 20000 */
     int32_t lanes_per_pose;  /* 0 = auto; 1, 2, 4 or 8 lanes cooperate on one pose row */
     int32_t lanes_per_lm;    /* 0 = auto */
     int32_t use_graphs;      /* 1 (default): replay the PCG iteration from a hipGraph */
     int32_t rank, world;     /* edge sharding: this process owns shard `rank` of `world` (default 0, 1) */
     int32_t verbose;
-    int32_t preconditioner;  /* 1 (default, single shard): smoothed-aggregation multigrid V-cycle on the reduced
-                                pose system; 0: block-Jacobi on its 3x3 diagonal (always used when world > 1) */
+    int32_t preconditioner;  /* 1 (default): smoothed-aggregation multigrid V-cycle on the reduced pose system; 0: block-Jacobi on its
+                                3x3 diagonal.  Edge-sharded runs (world > 1) take the same cycle: every rank builds the hierarchy's
+                                patterns from the whole graph (host memory: a full-graph layout + the hierarchy on every rank), the level-0
+                                blocks are all-reduced (rank 0 contributes the diagonal), everything below is computed redundantly. */
     int32_t xcd_map;         /* 1: workgroup -> slice map gives each XCD a contiguous eighth of the vertices; 0: round-robin */
     int32_t warm_start;      /* 0: PCG starts from zero.  1: from (1 - step) * the previous Gauss-Newton iteration's pose delta (the
                                 un-taken remainder of the last step).  2 (default): from the third solve on, extrapolated with the
@@ -78,6 +81,15 @@ typedef struct tsgo_config {
     int32_t reuse_structure; /* 1 (default): tsgo_set_graph with the SAME vertex ids/types, edge list and fixed list as the graph the
                                 handle already holds only refills estimates, measurements and weights (the reference re-creates
                                 everything per message, remote/app/ConnectionHandler.h:18-21); 0: always rebuild.  Same results. */
+    int32_t cycle_level0;    /* what the two level-0 products INSIDE the multigrid V-cycle read.  0 (default): the implicit Schur passes over
+                                the slot tables (f32 copy of the planes) — current with every linearisation; in an edge-sharded run each of
+                                them ends in an all-reduce.  1: the explicit level-0 matrix of the hierarchy (replicated on every shard, f32,
+                                as old as the hierarchy): no all-reduce inside the cycle, ~6 % more PCG iterations; what bench.py --gpus N
+                                (N > 1) runs.  The product PCG itself takes is always the implicit f64 one.  Same answers. */
+    int32_t cycle_storage;   /* 16 (default) or 32: how the copies of the hierarchy's matrices that the V-cycle reads (A_l, P_l, R_l, l >= 0) are
+                                stored — nine half floats with a common power-of-two exponent per 3x3 block (20 bytes), or nine f32 (36
+                                bytes).  A preconditioner tolerates the 11-bit blocks; PCG's own operator and every vector stay in
+                                `precision`.  Same answers, the same or one more PCG iteration per solve, fewer bytes per iteration. */
 } tsgo_config;
 
 enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_CONVERGED = 3, TSGO_STOP_SOLVER = 4 };
@@ -164,6 +176,21 @@ typedef struct tsgo_cycle_level {
     double us_per_sweep, bytes_per_sweep;
 } tsgo_cycle_level;
 int tsgo_cycle_probe(tsgo_optimizer* opt, int32_t reps, tsgo_cycle_level* out, int32_t cap);
+
+/* In-situ timing of ONE multigrid-preconditioned PCG iteration, kernel by kernel (bench.py's `roofline`): `reps` iterations are
+ * launched eagerly on the handle's stream with the stopping test disabled and a hipEvent recorded before every launch; an entry
+ * is one kernel instantiation at one place of the iteration (name = kernel symbol without arguments, `where` = level / role).
+ * us = average time from that launch's event to the next one's (the kernel in the cache state the solve leaves it in, plus
+ * one kernel boundary); bytes = the algorithmic bytes one such launch moves (the byte models of DESIGN.md section 4).  Returns
+ * the number of entries written (<= cap), in launch order; < 0 on error.  Block-Jacobi handles return their three kernels. */
+typedef struct tsgo_prof_entry {
+    char name[64];
+    char where[32];
+    int32_t launches_per_iteration;
+    int32_t reserved;
+    double us, bytes;
+} tsgo_prof_entry;
+int tsgo_profile_iteration(tsgo_optimizer* opt, int32_t reps, tsgo_prof_entry* out, int32_t cap);
 
 const char* tsgo_last_error(void);
 

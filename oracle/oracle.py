@@ -46,6 +46,11 @@ def set_odom_jacobian(kind):
     lib().oracle_set_odom_jacobian({"constant": 0, "analytic": 1}[kind])
 
 
+def set_cycle_level0(kind):
+    """"implicit" (default) or "explicit": what the twin's two products inside the multigrid cycle read (tsgo_config.cycle_level0)."""
+    lib().oracle_set_cycle_level0({"implicit": 0, "explicit": 1}[kind])
+
+
 def lib():
     global _LIB
     if _LIB is None:

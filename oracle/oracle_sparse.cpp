@@ -29,6 +29,7 @@
 #include "host/problem.h"
 #include "tsgo_math.h"
 
+static int g_cycle_level0 = 0;     // oracle_set_cycle_level0: 0 implicit Schur products inside the multigrid cycle, 1 the explicit level-0 matrix
 extern "C" int oracle_get_odom_jacobian(void);      // oracle_dense.cpp: 0 = the reference's constants, 1 = analytic (extension)
 
 namespace {
@@ -153,9 +154,9 @@ struct Twin {
             if (!amg.levels.empty()) for (int k = 0; k < 3; ++k) z[3 * (size_t)i + k] *= w0;
         }
         if (amg.levels.empty()) return;
-        // TSGO_CYCLE_EXPLICIT0=1 (the engine's switch of the same name, tsgo_hip.hip: launch_cycle_product): inside the cycle the
-        // product with the replicated EXPLICIT level-0 matrix — as old as the hierarchy — and no all-reduce
-        static const bool explicit0 = getenv("TSGO_CYCLE_EXPLICIT0") && atoi(getenv("TSGO_CYCLE_EXPLICIT0")) != 0;
+        // cycle_level0 = 1 (oracle_set_cycle_level0; the engine's tsgo_config.cycle_level0, tsgo_hip.hip: launch_cycle_product): inside
+        // the cycle the product with the replicated EXPLICIT level-0 matrix — as old as the hierarchy — and no all-reduce
+        const bool explicit0 = g_cycle_level0 != 0;
         auto cycle_product = [&] {
             if (explicit0) { amgtwin::Hierarchy::spmv(amg.levels[0].A, hier.A[0], z, s0); return; }
             schur_lm(z); schur_pose(z, s0); allreduce(s0.data(), (int64_t)s0.size());
@@ -364,13 +365,14 @@ struct Twin {
     // in gamma_ref the value the stopping rule compares against.  warm (optional): pose delta of the previous
     // Gauss-Newton iteration; PCG then starts from x0 = (1 - step) * warm, the un-taken remainder of that step
     // (r = b~ - S x0), and gamma_ref = gamma * (b^T D^-1 b) / (r0^T D^-1 r0) keeps the rule relative to b~.
-    double gamma_ref = 0;
+    double gamma_ref = 0, bdb = 0, rdr_start = 0;
     double linearize(const std::vector<double>* warm = nullptr) {
         lin_lm(); lin_pose();
         // gauge of owned poses goes into the partial so that it is summed exactly once across shards
         for (int i = pr.pose_first; i < pr.pose_last; ++i) { const double ga = pr.gauge_p[i] + lambda; part[(size_t)i * 18] += ga; part[(size_t)i * 18 + 3] += ga; part[(size_t)i * 18 + 5] += ga; }
         allreduce(part.data(), (int64_t)part.size());
         double g0 = finalize();
+        bdb = rdr_start = g0;           // b~^T D^-1 b~: what the multigrid PCG's stopping rule measures against (k_cg_step)
         double scale = 1;
         if (warm && warm->size() == x.size()) {
             for (size_t k = 0; k < x.size(); ++k) x[k] = (1.0 - step) * (*warm)[k];
@@ -385,7 +387,7 @@ struct Twin {
                 for (int k = 0; k < 3; ++k) nr += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
             }
             if (nr > 0 && g0 > nr) scale = g0 / nr;
-            g0 = nr;
+            g0 = nr; rdr_start = nr;
         }
         if (use_amg) {
             // the coarse matrices may lag the linearisation (level 0 never does): rebuilt after kHierMaxAge solves or
@@ -405,6 +407,9 @@ struct Twin {
     }
 
     // Chronopoulos-Gear PCG on the reduced (pose) system S x = b~.  Returns iterations.
+    // Stopping rule, both preconditioners: sqrt(r^T D^-1 r) <= tol sqrt(b~^T D^-1 b~), D = the 3x3 block diagonal of S.  With
+    // block-Jacobi that is gamma itself; under the multigrid cycle it is evaluated on the residual each step produces, BEFORE the
+    // cycle is applied to it (as k_cg_step does on the device: a finished solve does not pay one more cycle and product).
     int solve(double gamma_first, double tol, int max_it, bool* ok) {
         std::vector<double> buf((size_t)P * 3 + 1);
         const double gamma0 = gamma_ref;
@@ -412,9 +417,11 @@ struct Twin {
         *ok = true;
         if (!(gamma0 > 0)) return 0;
         int it = 0;
+        if (use_amg && rdr_start <= tol * tol * bdb) return 0;           // a warm start that already meets the rule (k_warm_scale)
         for (; it < max_it; ++it) {
             if (gamma < 0 || gamma != gamma) { *ok = false; break; }     // indefinite preconditioner: breakdown, not convergence
-            if (gamma <= tol * tol * gamma0) break;
+            if (!use_amg && gamma <= tol * tol * gamma0) break;
+            if (use_amg && !(gamma > 0)) break;                          // M^-1 r vanished
             schur_lm(z);
             buf[(size_t)P * 3] = schur_pose(z, buf);
             allreduce(buf.data(), (int64_t)buf.size());
@@ -431,15 +438,20 @@ struct Twin {
                     p[j] = z[j] + beta * p[j]; q[j] = buf[j] + beta * q[j];
                     x[j] += alpha * p[j]; r[j] -= alpha * q[j];
                 }
-                if (!use_amg) tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z[3 * (size_t)i], z[3 * (size_t)i + 1], z[3 * (size_t)i + 2]);
-                if (!use_amg) for (int k = 0; k < 3; ++k) gi[i] += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
-            }
-            if (use_amg) {
-                amg_apply();
-                for (int i = 0; i < P; ++i) for (int k = 0; k < 3; ++k) gi[i] += r[3 * (size_t)i + k] * z[3 * (size_t)i + k];
+                double z0, z1, z2;
+                tsgo::sym3_mul(&minv[6 * (size_t)i], r[3 * (size_t)i], r[3 * (size_t)i + 1], r[3 * (size_t)i + 2], z0, z1, z2);
+                gi[i] = r[3 * (size_t)i] * z0 + r[3 * (size_t)i + 1] * z1 + r[3 * (size_t)i + 2] * z2;      // r^T D^-1 r
+                if (!use_amg) { z[3 * (size_t)i] = z0; z[3 * (size_t)i + 1] = z1; z[3 * (size_t)i + 2] = z2; }
             }
             double gnew = 0;
             for (int i = 0; i < P; ++i) gnew += gi[i];       // serial: identical on every shard
+            if (use_amg) {
+                if (!(gnew > tol * tol * bdb)) { ++it; if (gnew != gnew) *ok = false; break; }      // this step's residual meets the rule: x is final
+                amg_apply();
+                gnew = 0;
+                for (int i = 0; i < P; ++i) { double g = 0; for (int k = 0; k < 3; ++k) g += r[3 * (size_t)i + k] * z[3 * (size_t)i + k]; gi[i] = g; }
+                for (int i = 0; i < P; ++i) gnew += gi[i];
+            }
             gamma_old = gamma; alpha_old = alpha; gamma = gnew;
         }
         if (use_amg) { iters_last = it; if (hier_age == 0) iters_fresh = it; if (hier_age >= 0) ++hier_age; if (!*ok) hier_age = -1; }
@@ -520,6 +532,7 @@ extern "C" {
 
 // OpenMP threads used by the twin's loops (a GPU box exposes far more logical CPUs than its share).
 void oracle_set_threads(int n) { omp_set_num_threads(n < 1 ? 1 : n); }
+void oracle_set_cycle_level0(int explicit_matrix) { g_cycle_level0 = explicit_matrix ? 1 : 0; }
 
 // One Gauss-Newton step at the given state: delta (3 per vertex, graph order; landmarks of other
 // shards are left 0), chi2, PCG iterations.  hook/ctx: all-reduce(sum) over shards, may be NULL.

@@ -348,6 +348,72 @@ def test_f32_mode_tracks_f64_loosely():
     np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=2e-3)            # f32 is NOT the parity mode
 
 
+def test_f32_mode_against_the_reference_servers_own_arithmetic():
+    """precision = 32 is the scalar type the reference server is compiled for (remote/app/main.cpp:40: OptimizerCpu<float>).  The
+    dense restatement in float (oracle_optimize_f32) IS that arithmetic; the f64 restatement is what both approximate.  Config 1,
+    10 iterations.  Stated bounds (measured: 1.1e-6 / 4.5e-6 / 2.2e-5): every chi^2 of the device's f32 run within 1e-4 of the f64
+    restatement and within 1e-4 of the float restatement with a Cholesky solve; vertices within 1e-3 of f64.
+    With the solver the reference really calls — colPivHouseholderQr (SolverEigen.h:20) — float arithmetic does NOT follow the
+    f64 path at all: Eigen's rank rule drops pivots below eps * n * |max pivot| = 1.2e-7 * 1134 * 1e6 (the gauge term), i.e.
+    nearly every unknown, and chi^2 creeps from 114586 to 95946 in 10 iterations instead of 12834.  That is the reference's own
+    float behaviour as restated; the device's f32 mode is held to the f64 answer instead, and is NOT compared with it."""
+    g = util.c1_arrays()
+    o = HipOptimizer(precision=32, pcg_rel_tol=1e-5)
+    try:
+        o.set_graph(g); r = o.optimize(10); v = o.vertices()
+    finally:
+        o.close()
+    ref64 = oracle.optimize(util.to_oracle(g), 10, mode="cpp", solver="chol")
+    ref32 = oracle.optimize(util.to_oracle(g), 10, mode="cpp", solver="chol", precision="f32")
+    qr32 = oracle.optimize(util.to_oracle(g), 10, mode="cpp", solver="qr", precision="f32")
+    assert r["iters"] == ref32["iters"] == 10
+    err_dev = np.abs(r["chi2"] / ref64["chi2"] - 1).max(); err_ref = np.abs(ref32["chi2"] / ref64["chi2"] - 1).max()
+    print("f32 at config 1: device vs f64 %.2e, dense float restatement (Cholesky) vs f64 %.2e, device vs float restatement %.2e; vertices vs f64 %.2e; float + pivoted QR ends at chi2 %.0f"
+          % (err_dev, err_ref, np.abs(r["chi2"] / ref32["chi2"] - 1).max(), util.max_vertex_diff(v, ref64["v_pos"], g.v_type), qr32["chi2"][-1]))
+    np.testing.assert_allclose(r["chi2"], ref64["chi2"], rtol=1e-4)
+    np.testing.assert_allclose(r["chi2"], ref32["chi2"], rtol=1e-4)
+    assert util.max_vertex_diff(v, ref64["v_pos"], g.v_type) < 1e-3
+    assert qr32["chi2"][-1] > 5 * ref64["chi2"][-1]          # documents the rank-rule effect described above
+
+
+@pytest.mark.parametrize("workload,chi_tol,pose_tol", [("c2_10k", 1e-5, 5e-2), ("c3_100k", 1e-5, 0.25)])
+def test_f32_mode_of_record_at_configs_2_and_3(workload, chi_tol, pose_tol):
+    """The f32 device mode (PCG tolerance 1e-5, what bench.py --precision 32 runs) against the f64 CPU twin after 10 GN
+    iterations at 10k and 100k poses.  Stated bound: chi^2 within 1e-5 relative at every iteration, vertices within 5e-2 m at 10k
+    poses and 0.25 m at 100k (measured: 1.6e-7 / 8e-3 and 4.2e-7 / 5e-2; f32 carries 7 digits, coordinates reach 10^2..10^3 m, ten 0.2-damped steps accumulate)."""
+    g = synth.make_config(workload)
+    ref = oracle.sparse_optimize(util.to_oracle(g), 10, pcg_tol=1e-10, precond="amg")
+    o = HipOptimizer(precision=32, pcg_rel_tol=1e-5)
+    try:
+        o.set_graph(g); r = o.optimize(10); v = o.vertices()
+    finally:
+        o.close()
+    assert (r["iters"], r["stop"]) == (ref["iters"], ref["stop"]) and r["fallbacks"] == 0
+    rel = np.abs(r["chi2"] / ref["chi2"] - 1).max(); dv = util.max_vertex_diff(v, ref["v_pos"], g.v_type)
+    print("f32 mode at %s: chi2 within %.2e of the f64 twin over 10 iterations, vertices within %.2e, PCG iterations %s" % (workload, rel, dv, list(r["cg_iters"])))
+    assert rel < chi_tol
+    assert dv < pose_tol
+
+
+def test_cycle_storage_16_and_32_give_the_same_answer():
+    """tsgo_config.cycle_storage: the V-cycle's copies of the hierarchy as packed half floats (default) against f32.  It only
+    preconditions: same chi^2 and vertices to solver tolerance, at most two more PCG iterations per solve."""
+    g = synth.make(8000, 10, loop_closures=50, seed=23)
+    g.fixed = np.array([0, int(g.v_id[-3])], np.uint32)          # a 1e6 gauge block next to ordinary ones: the per-block exponent's case
+    res = {}
+    for bits in (32, 16):
+        o = HipOptimizer(pcg_rel_tol=1e-12, cycle_storage=bits)
+        try:
+            o.set_graph(g); res[bits] = (o.optimize(6), o.vertices())
+        finally:
+            o.close()
+    (r32, v32), (r16, v16) = res[32], res[16]
+    np.testing.assert_allclose(r16["chi2"], r32["chi2"], rtol=1e-10)
+    assert util.max_vertex_diff(v16, v32, g.v_type) < 1e-9
+    assert r16["fallbacks"] == 0 and np.all(r16["cg_iters"] <= r32["cg_iters"] + 2), (r16["cg_iters"], r32["cg_iters"])
+    print("PCG iterations per solve, cycle storage f32 %s, packed half %s" % (list(r32["cg_iters"]), list(r16["cg_iters"])))
+
+
 def test_rejects_bad_graphs_without_crashing(opt):
     g = util.tiny_arrays("tiny_a")
     bad = g.copy(); bad.e_ids[1, 1] = 999
@@ -419,7 +485,7 @@ def test_multigrid_breakdown_falls_back_to_block_jacobi(monkeypatch):
         o.close()
     np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
     assert util.max_vertex_diff(v, vref, g.v_type) < 1e-7
-    assert r["fallbacks"] >= 0            # > 0 whenever the hierarchy is indefinite; either way the result holds
+    assert r["fallbacks"] >= 1            # the indefinite hierarchy was met and the block-Jacobi repeat answered
 
 
 @pytest.mark.parametrize("name", sorted(edge_cases.CASES))

@@ -168,9 +168,9 @@ def test_shards_whose_own_mean_degrees_straddle_a_lane_threshold():
     assert util.max_vertex_diff(_merge_landmarks(g, outs), vs, g.v_type) < 1e-8
 
 
-def test_one_all_reduce_per_iteration_variant_on_the_device(monkeypatch):
-    """What `bench.py --gpus N` runs (TSGO_CYCLE_EXPLICIT0=1, read by every handle when it is created): in-cycle products on the
-    replicated explicit level-0 matrix.  Three ranks against a single handle with the switch, and against the default form."""
+def test_one_all_reduce_per_iteration_variant_on_the_device():
+    """What `bench.py --gpus N` runs (tsgo_config.cycle_level0 = 1): in-cycle products on the replicated explicit level-0 matrix.
+    Three ranks against a single handle with the switch, and against the default form."""
     g = synth.make(6000, 10, loop_closures=40, seed=13)
     g.fixed = np.array([0, int(g.v_id[4000]), int(g.v_id[-5])], np.uint32)
     plain = HipOptimizer(pcg_rel_tol=1e-12)
@@ -178,8 +178,7 @@ def test_one_all_reduce_per_iteration_variant_on_the_device(monkeypatch):
         plain.set_graph(g); rp = plain.optimize(5); vp = plain.vertices()
     finally:
         plain.close()
-    monkeypatch.setenv("TSGO_CYCLE_EXPLICIT0", "1")
-    single = HipOptimizer(pcg_rel_tol=1e-12)
+    single = HipOptimizer(pcg_rel_tol=1e-12, cycle_level0="explicit")
     try:
         single.set_graph(g); rs = single.optimize(5); vs = single.vertices()
     finally:
@@ -187,10 +186,49 @@ def test_one_all_reduce_per_iteration_variant_on_the_device(monkeypatch):
     assert not np.array_equal(rs["cg_iters"], rp["cg_iters"])                    # the switch did change the preconditioner ...
     np.testing.assert_allclose(rs["chi2"], rp["chi2"], rtol=1e-10)               # ... and not the answer
     assert util.max_vertex_diff(vs, vp, g.v_type) < 1e-8
-    outs = _run_sharded(g, 3, 5, pcg_rel_tol=1e-12)
+    outs = _run_sharded(g, 3, 5, pcg_rel_tol=1e-12, cycle_level0="explicit")
     for r, _ in outs:
         np.testing.assert_allclose(r["chi2"], rs["chi2"], rtol=1e-10)
         np.testing.assert_array_equal(r["chi2"], outs[0][0]["chi2"])
         np.testing.assert_array_equal(r["cg_iters"], outs[0][0]["cg_iters"])
         assert r["fallbacks"] == 0 and np.all(np.abs(r["cg_iters"] - rs["cg_iters"]) <= 3), (r["cg_iters"], rs["cg_iters"])
     assert util.max_vertex_diff(_merge_landmarks(g, outs), vs, g.v_type) < 1e-8
+
+
+_C3 = {}
+
+
+def _c3_single(cycle):
+    """Config 3 (100k poses / 199k landmarks / 1.1M edges) through ONE handle: the reference every sharded run below is held to."""
+    if cycle not in _C3:
+        if "g" not in _C3:
+            _C3["g"] = synth.make_config("c3_100k")
+        o = HipOptimizer(pcg_rel_tol=1e-12, cycle_level0=cycle)
+        try:
+            o.set_graph(_C3["g"]); r = o.optimize(6); v = o.vertices()
+        finally:
+            o.close()
+        _C3[cycle] = (r, v)
+    return _C3["g"], _C3[cycle][0], _C3[cycle][1]
+
+
+@pytest.mark.parametrize("world", [2, 8])
+@pytest.mark.parametrize("cycle", ["implicit", "explicit"])
+def test_config_4_at_its_size_through_the_sharded_device_path(world, cycle):
+    """BASELINE config 4: the 100k-pose / 1M-LM-edge graph edge-sharded over 2 and over 8 ranks — here all on one GPU through the
+    in-process all-reduce group: 100k-pose shard tables, the 14.4 MB pose-partial and 2.4 MB product all-reduces, the 60 MB
+    level-0 all-reduce, eight ranks deciding alike — in both forms of the cycle (`--implicit-cycle` and the explicit-level-0 one
+    bench.py --gpus N runs).  Against the single-handle run of the same form (PCG tolerance 1e-12, so that what is compared is the
+    sharded arithmetic and not two solves' tolerances): same stop, PCG counts within 2, chi^2 to 1e-10, vertices to 1e-9; ranks
+    bit-identical."""
+    g, rs, vs = _c3_single(cycle)
+    outs = _run_sharded(g, world, 6, pcg_rel_tol=1e-12, cycle_level0=cycle)
+    for r, _ in outs:
+        assert (r["iters"], r["stop"]) == (rs["iters"], rs["stop"])
+        np.testing.assert_allclose(r["chi2"], rs["chi2"], rtol=1e-10)
+        np.testing.assert_array_equal(r["chi2"], outs[0][0]["chi2"])
+        np.testing.assert_array_equal(r["cg_iters"], outs[0][0]["cg_iters"])
+        assert r["fallbacks"] == 0
+        assert np.all(np.abs(r["cg_iters"] - rs["cg_iters"]) <= 2), (r["cg_iters"], rs["cg_iters"])
+        assert abs(r["delta_norm"] - rs["delta_norm"]) <= 1e-9 * rs["delta_norm"]
+    assert util.max_vertex_diff(_merge_landmarks(g, outs), vs, g.v_type) < 1e-9

@@ -255,6 +255,46 @@ def test_sharded_multigrid_lists_partition_the_whole_graphs_lists(world):
     assert pairs == whole.schur_contribs and odoms == od_whole.value and pairs > 0 and odoms > 0
 
 
+def test_eight_shards_of_config_3_all_reduce_buffers_of_equal_length():
+    """BASELINE config 4 at its size (100k poses / 1M LM edges, 8 ranks).  What the ranks all-reduce: [18 P + one chi^2 partial per
+    workgroup of the pose table] after the linearisation, [3 P + the same partials] after every Schur product, [9 x level-0
+    blocks] after k_schur_blocks.  Their lengths follow from P, the lanes per pose (pose-table shape) and the level-0 pattern:
+    all three must be the same on every rank (RCCL hangs otherwise), the landmark / pose ranges must tile the graph, and the
+    level-0 contribution lists must partition the unsharded ones."""
+    lib = _lib.host_lib()
+    g = synth.make_config("c3_100k")
+    cg = g.c_struct()
+    world = 8
+    infos = [probe(g, r, world) for r in range(world)]
+    assert len({(i.lanes_per_pose, i.lanes_per_lm, i.n_pose) for i in infos}) == 1
+    assert infos[0].lm_first == 0 and infos[-1].lm_last == g.n_landmarks and infos[0].pose_first == 0 and infos[-1].pose_last == g.n_poses
+    for a, b in zip(infos, infos[1:]):
+        assert a.lm_last == b.lm_first and a.pose_last == b.pose_first
+    assert sum(i.n_lm_edges_local for i in infos) == int((g.e_type == 1).sum())
+    share = np.array([i.n_lm_edges_local for i in infos], float)
+    assert share.max() / share.mean() < 1.02
+    whole = _lib.tsgo_amg_info(); od_whole = C.c_int64()
+    _lib.check(lib, lib.tsgo_amg_probe_shard(C.byref(cg), 0, 1, C.byref(whole), C.byref(od_whole)), "tsgo_amg_probe_shard")
+    pairs = odoms = 0
+    for rank in range(world):
+        info = _lib.tsgo_amg_info(); od = C.c_int64()
+        _lib.check(lib, lib.tsgo_amg_probe_shard(C.byref(cg), rank, world, C.byref(info), C.byref(od)), "tsgo_amg_probe_shard")
+        assert info.n_levels == whole.n_levels and list(info.rows) == list(whole.rows)
+        assert list(info.blocks) == list(whole.blocks) and list(info.p_blocks) == list(whole.p_blocks)     # blocks[0] x 9 = the 60 MB all-reduce
+        pairs += info.schur_contribs; odoms += od.value
+    assert pairs == whole.schur_contribs and odoms == od_whole.value
+
+
+def test_eight_shards_of_config_5_agree_on_the_pose_table_shape():
+    """The same shape rule at 1 M poses / 9.1 M edges (BASELINE config 5): first, a middle and the last of eight ranks."""
+    g = synth.make_config("c5_1m")
+    infos = [probe(g, r, 8) for r in (0, 3, 7)]
+    assert len({(i.lanes_per_pose, i.lanes_per_lm, i.n_pose) for i in infos}) == 1
+    assert infos[0].lm_first == 0 and infos[-1].lm_last == g.n_landmarks and infos[-1].pose_last == g.n_poses
+    share = np.array([i.n_lm_edges_local for i in infos], float)
+    assert share.max() / share.min() < 1.02
+
+
 def test_twin_python_rules_reproduce_the_reference_python_optimizer():
     """rules="python": the loop of python/optimizer/graph_optimizer.py:20-92 (lambda * I damping, step lr, b zeroed at fixed
     vertices).  Pinned by the 10-iteration trajectory the reference's own GraphOptimizer.optimize(10, lr=.2) produced

@@ -23,14 +23,13 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir, n_poses, precond, rules, explicit_cycle=False):
     sys.path.insert(0, ROOT)
-    if explicit_cycle:                 # read once per process by the twin (and by the engine): set before the first solve
-        os.environ["TSGO_CYCLE_EXPLICIT0"] = "1"
     torch.set_num_threads(2)      # also sizes the twin's OpenMP loops (same libgomp)
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
     from tests import util
     from toyslam_amd import synth
+    oracle.set_cycle_level0("explicit" if explicit_cycle else "implicit")       # the twin's side of tsgo_config.cycle_level0
     g = synth.make(n_poses, 10, loop_closures=30, seed=11)
     calls = [0]
 
@@ -74,9 +73,9 @@ def test_sharded_run_across_processes_matches_single_process(tmp_path, world, pr
 
 
 def test_one_all_reduce_per_iteration_variant_across_processes(tmp_path):
-    """What `bench.py --gpus N` runs (TSGO_CYCLE_EXPLICIT0=1): the two products inside the multigrid cycle read the replicated
+    """What `bench.py --gpus N` runs (tsgo_config.cycle_level0 = 1): the two products inside the multigrid cycle read the replicated
     explicit level-0 matrix, so only the PCG's own product is all-reduced.  Two processes against one, both with the switch
-    (each in a fresh process: the switch is read once), and against the default form's answer; the hook is called far less."""
+    , and against the default form's answer; the hook is called far less."""
     one = tmp_path / "one"; two = tmp_path / "two"; plain = tmp_path / "plain"
     for d in (one, two, plain):
         d.mkdir()

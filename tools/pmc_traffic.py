@@ -43,7 +43,12 @@ for k in sorted(set(fetch) | set(write)):
         live = [x for x in v if x > 0.05 * max(v)] if v else []
         return (statistics.median(live) if live else 0.0), len(v), len(live)
     f, nf, lf = med(fetch.get(k, [])); w, nw, lw = med(write.get(k, []))
-    kern[k] = {"fetch_kb_raw": f, "write_kb": w, "hbm_bytes_corrected": (2 * f + w) * 1024.0}
+
+    def mean_live(v):      # one symbol may run on several multigrid levels: the MEAN over its live dispatches is what a per-launch average needs
+        live = [x for x in v if x > 0.05 * max(v)] if v else []
+        return sum(live) / len(live) if live else 0.0
+    kern[k] = {"fetch_kb_raw": f, "write_kb": w, "hbm_bytes_corrected": (2 * f + w) * 1024.0,
+               "hbm_bytes_mean": (2 * mean_live(fetch.get(k, [])) + mean_live(write.get(k, []))) * 1024.0}
     lines.append("%-44s dispatches=%6d live=%6d  FETCH_SIZE median %12.1f KB  WRITE_SIZE median %12.1f KB  -> %8.2f MB corrected"
                  % (k, nf, lf, f, w, (2 * f + w) * 1024.0 / 1e6))
 # the instances tsgo_time_kernel launches (f64 slot planes, product mode), under the plain names bench.py's kernel table uses

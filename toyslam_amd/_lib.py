@@ -12,7 +12,7 @@ class tsgo_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("pcg_rel_tol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("lanes_per_pose", C.c_int32), ("lanes_per_lm", C.c_int32),
                 ("use_graphs", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("verbose", C.c_int32),
-                ("preconditioner", C.c_int32), ("xcd_map", C.c_int32), ("warm_start", C.c_int32), ("rules", C.c_int32), ("lr", C.c_double), ("odom_jacobian", C.c_int32), ("reuse_structure", C.c_int32)]
+                ("preconditioner", C.c_int32), ("xcd_map", C.c_int32), ("warm_start", C.c_int32), ("rules", C.c_int32), ("lr", C.c_double), ("odom_jacobian", C.c_int32), ("reuse_structure", C.c_int32), ("cycle_level0", C.c_int32), ("cycle_storage", C.c_int32)]
 
 
 class tsgo_stats(C.Structure):
@@ -27,6 +27,11 @@ class tsgo_stats(C.Structure):
 class tsgo_cycle_level(C.Structure):
     _fields_ = [("rows", C.c_int64), ("blocks", C.c_int64), ("sweeps_per_cycle", C.c_int32), ("lanes_per_row", C.c_int32),
                 ("us_per_sweep", C.c_double), ("bytes_per_sweep", C.c_double)]
+
+
+class tsgo_prof_entry(C.Structure):
+    _fields_ = [("name", C.c_char * 64), ("where", C.c_char * 32), ("launches_per_iteration", C.c_int32), ("reserved", C.c_int32),
+                ("us", C.c_double), ("bytes", C.c_double)]
 
 
 class tsgo_synth_config(C.Structure):
@@ -51,7 +56,7 @@ HOST_SYMBOLS = ["tsgo_default_config", "tsgo_last_error", "tsgo_wire_decode", "t
                 "tsgo_wire_encode_response", "tsgo_wire_encode_request", "tsgo_synth_create", "tsgo_synth_view",
                 "tsgo_synth_truth", "tsgo_synth_free", "tsgo_layout_probe", "tsgo_amg_probe", "tsgo_amg_probe_shard"]
 DEVICE_SYMBOLS = ["tsgo_create", "tsgo_destroy", "tsgo_set_graph", "tsgo_optimize", "tsgo_get_vertices",
-                  "tsgo_linearize", "tsgo_solve_step", "tsgo_comm_unique_id", "tsgo_comm_init", "tsgo_time_kernel", "tsgo_cycle_probe", "tsgo_local_group_create", "tsgo_local_group_destroy", "tsgo_comm_init_local"]
+                  "tsgo_linearize", "tsgo_solve_step", "tsgo_comm_unique_id", "tsgo_comm_init", "tsgo_time_kernel", "tsgo_cycle_probe", "tsgo_profile_iteration", "tsgo_local_group_create", "tsgo_local_group_destroy", "tsgo_comm_init_local"]
 
 
 def _declare_host(L):
@@ -89,6 +94,7 @@ def _declare_device(L):
     L.tsgo_comm_init.argtypes = [vp, vp]
     L.tsgo_time_kernel.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tsgo_cycle_probe.argtypes = [vp, C.c_int32, C.POINTER(tsgo_cycle_level), C.c_int32]
+    L.tsgo_profile_iteration.argtypes = [vp, C.c_int32, C.POINTER(tsgo_prof_entry), C.c_int32]
     L.tsgo_local_group_create.argtypes = [C.c_int32, C.POINTER(vp)]
     L.tsgo_local_group_destroy.argtypes = [vp]; L.tsgo_local_group_destroy.restype = None
     L.tsgo_comm_init_local.argtypes = [vp, vp]

@@ -130,6 +130,7 @@ struct Server {
     struct Bytes {
         std::unique_ptr<uint8_t[]> p; size_t cap = 0, n = 0;
         void resize(size_t want) { if (want > cap) { cap = want + want / 4; p.reset(new uint8_t[cap]); } n = want; }
+        void shrink_to(size_t keep) { if (cap > keep) { p.reset(); cap = 0; n = 0; } }
         uint8_t* data() { return p.get(); }
         size_t size() const { return n; }
     };
@@ -184,18 +185,37 @@ struct Server {
         return write_all(fd, reply.data(), reply.size());
     }
 
+    // The size prefix is a signed 32-bit int (ConnectionHandlerGraph.h:37-43,57): up to 2 GiB on the wire.  A connection's buffers
+    // are grow-only and the process keeps freed pages (mallopt in main), so one oversized or hostile prefix would pin gigabytes for
+    // good: messages above max_message_bytes are refused (the connection is closed, like any malformed request), and a session
+    // whose buffers are more than 4x its last few requests gives them back.
+    size_t max_message_bytes = size_t(1) << 30;
     void connection(int fd) {
         std::cout << "\n------ New Connection ------\n";                         // ConnectionHandler.h:10
         int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
-        Session ss;
-        Bytes& payload = ss.payload;
-        for (;;) {
-            int32_t size = 0;                                                    // ConnectionHandlerGraph.h:37-43,57
-            if (!read_exact(fd, &size, sizeof(size))) break;
-            if (size <= 0) { std::cerr << "bad graph size " << size << std::endl; break; }
-            payload.resize((size_t)size);
-            if (!read_exact(fd, payload.data(), payload.size())) break;
-            if (!handle(fd, ss)) break;
+        try {                                        // bad_alloc and friends end THIS connection, not the server (the thread is detached)
+            Session ss;
+            Bytes& payload = ss.payload;
+            size_t window_max = 0; int window_n = 0;
+            for (;;) {
+                int32_t size = 0;                                                // ConnectionHandlerGraph.h:37-43,57
+                if (!read_exact(fd, &size, sizeof(size))) break;
+                if (size <= 0) { std::cerr << "bad graph size " << size << std::endl; break; }
+                if ((size_t)size > max_message_bytes) { std::cerr << "graph size " << size << " exceeds the server's limit of " << max_message_bytes << " bytes (TSGO_MAX_MESSAGE_MB)" << std::endl; break; }
+                // every 8 messages: buffers more than 4x the largest of them go back to the allocator
+                window_max = std::max(window_max, (size_t)size);
+                if (++window_n == 8) {
+                    if (payload.cap > 4 * window_max) { payload.shrink_to(0); ss.reply.shrink_to(0); std::vector<double>().swap(ss.v_pos); tsgo_wire_free(ss.w); ss.w = tsgo_wire_new(); }
+                    window_max = 0; window_n = 0;
+                }
+                payload.resize((size_t)size);
+                if (!read_exact(fd, payload.data(), payload.size())) break;
+                if (!handle(fd, ss)) break;
+            }
+        } catch (const std::exception& e) {
+            std::cerr << "connection error: " << e.what() << std::endl;
+        } catch (...) {
+            std::cerr << "connection error: unknown exception" << std::endl;
         }
         ::close(fd);
     }
@@ -240,6 +260,7 @@ int main(int argc, char* argv[]) {
         }
         if (odomS == "analytic") { cfg.odom_jacobian = 1; std::cout << "ODOM Jacobians: analytic (extension)\n"; }
         Server srv; srv.iterations = iters; srv.cfg = cfg; srv.max_engines = engines;
+        if (const char* e = getenv("TSGO_MAX_MESSAGE_MB")) srv.max_message_bytes = (size_t)std::max(1, atoi(e)) << 20;
         {   // fail at start-up, like the reference, when the pipeline cannot be created at all
             tsgo_optimizer* first = srv.acquire();
             if (!first) { std::cerr << "ConnectionManager error: " << tsgo_last_error() << std::endl; return 1; }

@@ -6,6 +6,7 @@
 // 100k poses): those kernels are latency-bound by design and kept deliberately simple; the bytes are
 // in level 0, whose residuals reuse the implicit Schur passes of tsgo_kernels.h.
 #pragma once
+#include <hip/hip_fp16.h>
 #include <hip/hip_runtime.h>
 
 #include "tsgo_kernels.h"
@@ -280,19 +281,75 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_inverse(int nb, const i
 // The setup kernels address 3x3 blocks by block index (36 contiguous bytes, "AoS").  Read that way by the cycle kernels —
 // a lane per block, nine loads — every load instruction of a wavefront touches 36-byte-strided words: 18+ cache lines
 // for 256 useful bytes, and the texture addressers, not the memory system, set the pace (profiles/r01e: L1 tag pipes at
-// 40 %).  The cycle therefore reads a COPY in which the blocks of one row are stored plane-major: element m of the j-th
-// block of row i lives at 9 * ptr[i] + m * len_i + j, so that lanes j, j+1, ... load consecutive words.  Same bytes, one
-// or two lines per load instruction.  The copy is written once per hierarchy build (k_to_planes, 8 lanes per row).
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_to_planes(int n_rows, const int* __restrict__ ptr, const HT<T>* __restrict__ src, HT<T>* __restrict__ dst) {
+// 40 %).  The cycle therefore reads a COPY in which the blocks of one row are stored plane-major: word m of the j-th
+// block of row i lives at W * ptr[i] + m * len_i + j, so that lanes j, j+1, ... load consecutive words.  One or two lines per
+// load instruction.  The copy is written once per hierarchy build (k_to_planes, 8 lanes per row).  Two encodings:
+//   PK = 0: W = 9 words, the block's nine f32 values.
+//   PK = 1 (tsgo_config.cycle_storage = 16, default): W = 5 words = nine IEEE half floats + a power-of-two exponent (int16) common
+//           to the block: value_k = half_k * 2^e, e chosen so that the block's largest entry sits in [2^14, 2^15) — eleven
+//           significant bits relative to the block's own maximum whatever its magnitude (gauge blocks of 1e6 next to 1e-3).
+//           20 bytes per block instead of 36 and five loads instead of nine: the sweeps of the big levels are byte-bound at
+//           1 M poses and half byte-, half latency-bound at 100 k.  A block and its mirror (A_ij, A_ji^T) have the same maximum,
+//           hence the same exponent and element-wise the same rounding: the rounded matrix is still symmetric, and because
+//           every use inside the cycle (pre-sweeps, residual, post-sweeps; restriction and prolongation through R = P^T copies of
+//           the same rounded blocks) reads THIS copy, the V-cycle stays a symmetric operator.  The setup (Galerkin products,
+//           diagonal inverses) keeps the f32 blocks.
+constexpr int kCyWordsF32 = 9, kCyWordsF16 = 5;
+template <int PK> __host__ __device__ constexpr int cy_words() { return PK ? kCyWordsF16 : kCyWordsF32; }
+
+// the j-th block of a row whose cycle-format words start at `base` (row length len), as nine values of type T
+template <typename T, int PK> __device__ __forceinline__ void cy_load(const uint32_t* __restrict__ base, size_t len, size_t j, T* b) {
+    const uint32_t* q = base + j;
+    if (PK) {
+        uint32_t w[5];
+#pragma unroll
+        for (int m = 0; m < 5; ++m) w[m] = q[(size_t)m * len];
+        const int e = (int)(short)(w[4] >> 16);
+        const float sc = __uint_as_float((uint32_t)(e + 127) << 23);          // 2^e, e in [-126, 127] by construction
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            b[2 * m] = T(__half2float(__ushort_as_half((unsigned short)(w[m] & 0xffffu))) * sc);
+            b[2 * m + 1] = T(__half2float(__ushort_as_half((unsigned short)(w[m] >> 16))) * sc);
+        }
+        b[8] = T(__half2float(__ushort_as_half((unsigned short)(w[4] & 0xffffu))) * sc);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 9; ++m) b[m] = T(__uint_as_float(q[(size_t)m * len]));
+    }
+}
+
+template <typename T, int PK>
+__global__ __launch_bounds__(kBlock) void k_to_planes(int n_rows, const int* __restrict__ ptr, const HT<T>* __restrict__ src, uint32_t* __restrict__ dst) {
     const int g = (blockIdx.x * kBlock + threadIdx.x) / 8, sub = threadIdx.x % 8;
     if (g >= n_rows) return;
     const int p0 = ptr[g], len = ptr[g + 1] - p0;
+    constexpr int W = cy_words<PK>();
     for (int j = sub; j < len; j += 8) {
         const HT<T>* b = src + (size_t)(p0 + j) * 9;
-        HT<T>* o = dst + (size_t)p0 * 9 + j;
+        uint32_t* o = dst + (size_t)p0 * W + j;
+        float v[9];
 #pragma unroll
-        for (int m = 0; m < 9; ++m) o[(size_t)m * len] = b[m];
+        for (int m = 0; m < 9; ++m) v[m] = (float)b[m];
+        if (PK) {
+            float mx = 0;
+#pragma unroll
+            for (int m = 0; m < 9; ++m) mx = fmaxf(mx, fabsf(v[m]));
+            int e = 0;
+            if (mx > 0.f && mx < 3.0e38f) {
+                e = ilogbf(mx) - 14;                                  // largest entry -> [2^14, 2^15)
+                e = e < -126 ? -126 : (e > 112 ? 112 : e);            // 2^e and 2^-e stay normal floats
+            }
+            const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+            unsigned short h[9];
+#pragma unroll
+            for (int m = 0; m < 9; ++m) h[m] = __half_as_ushort(__float2half_rn(v[m] * inv));
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o[(size_t)m * len] = (uint32_t)h[2 * m] | ((uint32_t)h[2 * m + 1] << 16);
+            o[(size_t)4 * len] = (uint32_t)h[8] | ((uint32_t)(unsigned short)(short)e << 16);
+        } else {
+#pragma unroll
+            for (int m = 0; m < 9; ++m) o[(size_t)m * len] = __float_as_uint(v[m]);
+        }
     }
 }
 
@@ -303,10 +360,10 @@ __global__ __launch_bounds__(kBlock) void k_to_planes(int n_rows, const int* __r
 
 // MODE 0: out = r - A z.   MODE 1: out = z + omega Dinv (r - A z)  (smoothing sweep).
 // MODE 2: out = Dinv A z  (power iteration for the smoother's damping).
-// PM: A is the plane-major copy (cycle format above); otherwise block-indexed.
-template <typename T, int LPR, int MODE, int PM = 1>
+// PM: A is the cycle-format copy (above; PK = its encoding); otherwise the block-indexed f32 / HT matrix.
+template <typename T, int LPR, int MODE, int PM = 1, int PK = 0>
 __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __restrict__ ptr, const int* __restrict__ col,
-                                                          const HT<T>* __restrict__ A, const T* __restrict__ r, const T* __restrict__ z,
+                                                          const void* __restrict__ Av, const T* __restrict__ r, const T* __restrict__ z,
                                                           const HT<T>* __restrict__ Dinv, T* __restrict__ out,
                                                           const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
     if (MODE != 2 && st->done) return;
@@ -329,16 +386,13 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
         }
     }
     const size_t len = (size_t)(p1 - p0);
-    const HT<T>* base = A + (size_t)p0 * 9;
+    const uint32_t* base = (const uint32_t*)Av + (size_t)p0 * cy_words<PK>();
     for (int a = p0 + sub; a < p1; a += LPR) {
         const T* v = z + (size_t)col[a] * 3;
         T b[9];
-        if (PM) {
-            const HT<T>* q = base + (a - p0);
-#pragma unroll
-            for (int m = 0; m < 9; ++m) b[m] = q[(size_t)m * len];
-        } else {
-            const HT<T>* q = A + (size_t)a * 9;
+        if (PM) cy_load<T, PK>(base, len, (size_t)(a - p0), b);
+        else {
+            const HT<T>* q = (const HT<T>*)Av + (size_t)a * 9;
 #pragma unroll
             for (int m = 0; m < 9; ++m) b[m] = q[m];
         }
@@ -365,8 +419,8 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
 
 // out = A z with z stored at row stride `zs` (research, TSGO_CYCLE_EXPLICIT0: the explicit level-0 matrix in place of the
 // implicit Schur product inside the cycle; z is the pose-record array zc, stride kPoseRec).  A plane-major (cycle format).
-template <typename T, int LPR>
-__global__ __launch_bounds__(kBlock) void k_bcsr_apply(int n, const int* __restrict__ ptr, const int* __restrict__ col, const HT<T>* __restrict__ A,
+template <typename T, int LPR, int PK>
+__global__ __launch_bounds__(kBlock) void k_bcsr_apply(int n, const int* __restrict__ ptr, const int* __restrict__ col, const uint32_t* __restrict__ A,
                                                        const T* __restrict__ z, int zs, T* __restrict__ out, const CgState<T>* __restrict__ st) {
     if (st->done) return;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
@@ -374,13 +428,11 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_apply(int n, const int* __restr
     T s0 = 0, s1 = 0, s2 = 0;
     const int p0 = ptr[i], p1 = ptr[i + 1];
     const size_t len = (size_t)(p1 - p0);
-    const HT<T>* base = A + (size_t)p0 * 9;
+    const uint32_t* base = A + (size_t)p0 * cy_words<PK>();
     for (int a = p0 + sub; a < p1; a += LPR) {
         const T* v = z + (size_t)col[a] * zs;
-        const HT<T>* q = base + (a - p0);
         T b[9];
-#pragma unroll
-        for (int m = 0; m < 9; ++m) b[m] = q[(size_t)m * len];
+        cy_load<T, PK>(base, len, (size_t)(a - p0), b);
         const T v0 = v[0], v1 = v[1], v2 = v[2];
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
@@ -390,9 +442,9 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_apply(int n, const int* __restr
 
 // rc = P^T v over the rows of R = P^T, and (when dinv_next is given) the next level's pre-smoothing
 // z_next = Dinv_next rc in the same pass.  SUB: v = a - b (level 0: r - S z, never materialised).
-template <typename T, int LPR, int SUB>
+template <typename T, int LPR, int SUB, int PK = 0>
 __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
-                                                     const HT<T>* __restrict__ Rv, const T* __restrict__ va,
+                                                     const uint32_t* __restrict__ Rv, const T* __restrict__ va,
                                                      const T* __restrict__ vb, T* __restrict__ rc, const HT<T>* __restrict__ dinv_next,
                                                      T* __restrict__ z_next, const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
     if (st->done) return;
@@ -409,12 +461,11 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
         for (int m = 0; m < 9; ++m) dn[m] = dinv_next[(size_t)a * 9 + m];
     }
     const size_t len = (size_t)(p1 - p0);
-    const HT<T>* base = Rv + (size_t)p0 * 9;          // plane-major within the row (cycle format)
+    const uint32_t* base = Rv + (size_t)p0 * cy_words<PK>();          // cycle format
     for (int rb = p0 + sub; rb < p1; rb += LPR) {
-        const HT<T>* q = base + (rb - p0); const size_t i = (size_t)rcol[rb] * 3;
+        const size_t i = (size_t)rcol[rb] * 3;
         T b[9];
-#pragma unroll
-        for (int m = 0; m < 9; ++m) b[m] = q[(size_t)m * len];
+        cy_load<T, PK>(base, len, (size_t)(rb - p0), b);
         T x0 = va[i], x1 = va[i + 1], x2 = va[i + 2];
         if (SUB) { x0 -= vb[i]; x1 -= vb[i + 1]; x2 -= vb[i + 2]; }
         s0 += b[0] * x0 + b[1] * x1 + b[2] * x2; s1 += b[3] * x0 + b[4] * x1 + b[5] * x2; s2 += b[6] * x0 + b[7] * x1 + b[8] * x2;
@@ -431,9 +482,9 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
 }
 
 // z_i += sum_a P_ia e_a; z has row stride `zs` (3 on coarse levels, kPoseRec for zc)
-template <typename T, int LPR>
+template <typename T, int LPR, int PK = 0>
 __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __restrict__ pptr, const int* __restrict__ pcol,
-                                                        const HT<T>* __restrict__ P, const T* __restrict__ e, T* __restrict__ z, int zs,
+                                                        const uint32_t* __restrict__ P, const T* __restrict__ e, T* __restrict__ z, int zs,
                                                         const CgState<T>* __restrict__ st) {
     if (st->done) return;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
@@ -444,12 +495,11 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
     T z0 = 0, z1 = 0, z2 = 0;                          // the entry this row adds to: read before the walk
     if (head) { z0 = z[(size_t)i * zs]; z1 = z[(size_t)i * zs + 1]; z2 = z[(size_t)i * zs + 2]; }
     const size_t len = (size_t)(p1 - p0);
-    const HT<T>* base = P + (size_t)p0 * 9;           // plane-major within the row (cycle format)
+    const uint32_t* base = P + (size_t)p0 * cy_words<PK>();           // cycle format
     for (int pb = p0 + sub; pb < p1; pb += LPR) {
-        const HT<T>* q = base + (pb - p0); const T* v = e + (size_t)pcol[pb] * 3;
+        const T* v = e + (size_t)pcol[pb] * 3;
         T b[9];
-#pragma unroll
-        for (int m = 0; m < 9; ++m) b[m] = q[(size_t)m * len];
+        cy_load<T, PK>(base, len, (size_t)(pb - p0), b);
         const T v0 = v[0], v1 = v[1], v2 = v[2];
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
@@ -541,33 +591,24 @@ __global__ __launch_bounds__(kBlock) void k_norm2(int n3, const T* __restrict__ 
     if (threadIdx.x == 0) part[blockIdx.x] = total;
 }
 
-// r^T D^-1 r partials (D = the 3x3 Schur diagonal): an SPD norm of the residual that does not involve the
-// multigrid operator, used once per solve to certify convergence independently of the preconditioner.
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_resid_norm(int P, const T* __restrict__ minv, const T* __restrict__ r, T* __restrict__ part) {
-    __shared__ T red[kWavesPerBlock];
-    const int i = blockIdx.x * kBlock + threadIdx.x;
-    T g = 0;
-    if (i < P) {
-        T z0, z1, z2;
-        const T r0 = r[(size_t)i * 3], r1 = r[(size_t)i * 3 + 1], r2 = r[(size_t)i * 3 + 2];
-        sym3_mul<T>(minv + (size_t)i * 6, r0, r1, r2, z0, z1, z2);
-        g = r0 * z0 + r1 * z1 + r2 * z2;
-    }
-    const T total = block_sum<T>(g, red);
-    if (threadIdx.x == 0) part[blockIdx.x] = total;
-}
-
 // PCG vector step when the preconditioner is applied by separate kernels (the V-cycle):
 //   gamma = (r, z), delta = (S z, z) arrive as partials; p = z + beta p, q = S z + beta q,
 //   x += alpha p, r -= alpha q.  z for the next iteration comes from the next V-cycle.
+// Stopping rule: sqrt(r^T D^-1 r) <= tol * sqrt(b^T D^-1 b), D = the 3x3 block diagonal of S (minv = D^-1; the b-side partials
+// were left in bpart by k_pose_finalize) — the rule block-Jacobi PCG applies as well, and a norm the multigrid operator has no
+// part in.  It is evaluated on the residual THIS step produces: the level-0 pre-smoothing below computes D^-1 r anyway, every
+// workgroup leaves its partial of r^T D^-1 r, and k_iter_gate — one workgroup, first kernel of the next iteration — sums them
+// and sets `done`: a converged solve does not run one more V-cycle and product just to learn that it was finished (the rule on
+// r^T M^-1 r could only be tested after applying M^-1).  (The sum inside this kernel by the last-arriving workgroup was measured:
+// its agent-scope release drains the 24 MB this kernel has just written, 12 -> 30 us; profiles/r03b_*.)
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__ sz, const T* __restrict__ dot_part,
                                                     const T* __restrict__ rz_part, int n_part, const CgState<T>* __restrict__ st_in,
                                                     CgState<T>* __restrict__ st_out, T* __restrict__ r, T* __restrict__ p,
                                                     T* __restrict__ q, T* __restrict__ x, T* __restrict__ zc,
                                                     const T* __restrict__ minv, const T* __restrict__ omega_ptr, T tol2, int max_iters,
-                                                    const T* __restrict__ gamma0_scale, int stall_iter, T stall_ratio) {
+                                                    const T* __restrict__ gamma0_scale, int stall_iter, T stall_ratio,
+                                                    T* __restrict__ rdr_part) {
     __shared__ T red[kWavesPerBlock];
     const CgState<T> s = *st_in;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
@@ -576,10 +617,10 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
     const T gamma = block_sum_array<T>(rz_part, n_part, red);
     const T gamma0 = s.iters == 0 ? gamma * (*gamma0_scale) : s.gamma0;
     CgState<T> n = s; n.gamma0 = gamma0;
-    if (!(gamma > tol2 * gamma0) || s.iters >= max_iters) {
-        // gamma = r^T M^-1 r < 0 (or NaN) means the preconditioner is not positive definite: breakdown,
-        // NOT convergence (the host then repeats the solve with block-Jacobi)
-        n.done = 1; n.fail = (gamma != gamma || gamma < T(0)) ? 1 : ((gamma > tol2 * gamma0) ? 2 : 0);
+    // gamma = r^T M^-1 r < 0 (or NaN) means the preconditioner is not positive definite: breakdown, NOT convergence (the host then
+    // repeats the solve with block-Jacobi); gamma == 0: M^-1 r vanished, nothing left to correct; the cap: unconverged
+    if (!(gamma > T(0)) || s.iters >= max_iters) {
+        n.done = 1; n.fail = (gamma != gamma || gamma < T(0)) ? 1 : (gamma > T(0) ? 2 : 0);
         if (writer) *st_out = n;
         return;
     }
@@ -590,6 +631,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
     else { beta = gamma / s.gamma_old; alpha = gamma / (delta - beta * gamma / s.alpha_old); }
     if (!(alpha > 0) || !(alpha < T(1e300))) { n.done = 1; n.fail = 1; if (writer) *st_out = n; return; }
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    T g = 0;
     if (i < P) {
         T rr[3];
 #pragma unroll
@@ -605,8 +647,22 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
         const T w = *omega_ptr;
         T* zr = zc + (size_t)i * kPoseRec;
         zr[0] = w * z0; zr[1] = w * z1; zr[2] = w * z2;
+        g = rr[0] * z0 + rr[1] * z1 + rr[2] * z2;
     }
+    const T total = block_sum<T>(g, red);
+    if (threadIdx.x == 0) rdr_part[blockIdx.x] = total;
     if (writer) { n.gamma_old = gamma; n.alpha_old = alpha; n.iters = s.iters + 1; *st_out = n; }
+}
+
+// First kernel of every multigrid-preconditioned PCG iteration, one workgroup: has the residual the last k_cg_step produced met the
+// stopping rule?  Then this and every later kernel of the solve exits at once (they all read st->done).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_iter_gate(CgState<T>* __restrict__ st, const T* __restrict__ rdr_part, const T* __restrict__ bpart, int n, T tol2) {
+    __shared__ T red[kWavesPerBlock];
+    if (st->done || st->iters == 0) return;          // iteration 0: no step has been taken yet (a warm start is judged by k_warm_scale)
+    const T rdr = block_sum_array<T>(rdr_part, n, red);
+    const T bdb = block_sum_array<T>(bpart, n, red);
+    if (threadIdx.x == 0 && !(rdr > tol2 * bdb)) { st->done = 1; st->fail = (rdr != rdr) ? 1 : 0; }      // NaN: breakdown
 }
 
 }  // namespace tsgo

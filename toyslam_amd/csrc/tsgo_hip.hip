@@ -11,6 +11,7 @@
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
+#include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -123,6 +124,7 @@ struct IEngine {
     virtual int solve_step(double* delta, double* chi2, int* iters) = 0;
     virtual int time_kernel(int which, int reps, double* us, double* bytes) = 0;
     virtual int cycle_probe(int reps, tsgo_cycle_level* out, int cap) = 0;
+    virtual int profile_iteration(int reps, tsgo_prof_entry* out, int cap) = 0;
     ncclComm_t comm = nullptr;
     tsgo_local_group* lgroup = nullptr;      // in-process stand-in for the communicator (tests on a one-GPU box)
 };
@@ -135,12 +137,19 @@ constexpr double kAmgStallRatio = 0.5;  // failed preconditioner (stagnation) an
 constexpr double kMediumPairList = 6;   // Galerkin products whose average pair list is longer than this share an output block among 8 lanes,
 constexpr double kLongPairList = 16;    // ... longer than this among 16 lanes ...
 constexpr double kVeryLongPairList = 200; // ... or a whole wavefront
-constexpr double kCertifySlack = 1e4;   // certificate: sqrt(r^T D^-1 r / b^T D^-1 b) <= slack * tol (norms differ by up to ~sqrt(cond))
 constexpr int kHierMaxAge = 2;          // a multigrid hierarchy serves at most this many consecutive linearisations ...
 constexpr int kHierSlack = 2;           // ... and is rebuilt as soon as a solve needs more than this many iterations over its first
 constexpr int kHierFreshAbove = 64;     // ... and at every linearisation while solves take more iterations than this (a build costs about four)
+constexpr double kProfBlockUsPerLaunch = 10.0;   // tsgo_profile_iteration: host time allowed per enqueued launch + event behind the blocking kernel
 constexpr int kChunk = 16;   // PCG iterations per captured hipGraph (even: the state ring has 2 slots)
 constexpr int kChunkAmg = 2; // with the multigrid V-cycle an iteration is ~30 launches and a solve ~50 iterations
+
+// Holds its stream for `ms` milliseconds (constant-rate 100 MHz counter), bounded: at most a few hundred ms whatever is asked.
+__global__ void k_wait_ms(int ms) {
+    const long long ticks = (long long)(ms < 0 ? 0 : (ms > 400 ? 400 : ms)) * 100000ll;
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
 
 template <typename T> struct DevLevel {      // device copy of one AmgLevel (host/amg.h) + its numeric arrays
     int n = 0, n_agg = 0, nnzA = 0, nnzP = 0, nnzT = 0, nnzNext = 0;
@@ -153,7 +162,7 @@ template <typename T> struct DevLevel {      // device copy of one AmgLevel (hos
     using H = HT<T>;                              // hierarchy storage type (tsgo_amg_kernels.h)
     T* rel = nullptr;
     H *A = nullptr, *Dinv = nullptr, *P = nullptr, *Tv = nullptr, *Rv = nullptr;
-    H *Apm = nullptr, *Ppm = nullptr, *Rpm = nullptr;       // cycle format: the same blocks, plane-major within each row (tsgo_amg_kernels.h)
+    uint32_t *Apm = nullptr, *Ppm = nullptr, *Rpm = nullptr;       // cycle format: the same blocks, plane-major within each row, f32 or packed half (tsgo_amg_kernels.h)
     T *r = nullptr, *z = nullptr, *res = nullptr, *z2 = nullptr;
 };
 
@@ -230,17 +239,20 @@ template <typename T> struct Engine : IEngine {
         return lv[l].n <= kSmallLevelRows ? kSmallLevelSweeps : coarse_sweeps;
     }
     bool low_cycle = true;     // f32 slot planes for the Schur products inside the multigrid cycle
+    bool cy16 = true;          // tsgo_config.cycle_storage: the cycle-format copies of A_l, P_l, R_l as packed half floats (20 B per block) or f32 (36 B)
+    size_t cyw() const { return cy16 ? (size_t)kCyWordsF16 : (size_t)kCyWordsF32; }
 
     explicit Engine(const tsgo_config& c) : cfg(c) {
         if (const char* e = getenv("TSGO_COARSE_SWEEPS")) { coarse_sweeps = std::max(1, std::min(4, atoi(e))); sweeps_forced = true; }
         if (const char* e = getenv("TSGO_SWEEPS_LIST")) for (const char* q = e; *q;) { sweeps_list.push_back(std::max(1, std::min(4, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
         if (const char* e = getenv("TSGO_CYCLE_F64")) low_cycle = atoi(e) == 0;
-        if (const char* e = getenv("TSGO_CYCLE_EXPLICIT0")) explicit0 = atoi(e) != 0;
+        explicit0 = c.cycle_level0 != 0;
+        cy16 = c.cycle_storage != 32;
         if (const char* e = getenv("TSGO_HIER_MAX_AGE")) hier_max_age = std::max(1, atoi(e));
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
 
-    ~Engine() override { release(); for (Slab& sl : slabs) (void)hipFree(sl.base); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); }
+    ~Engine() override { release(); for (Slab& sl : slabs) (void)hipFree(sl.base); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); for (auto& m : prof) (void)hipEventDestroy(m.e); }
 
     void release() {
         if (amg_builder.joinable()) amg_builder.join();
@@ -368,11 +380,11 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&D.P, (size_t)D.nnzP * 9)) return rc;
         if (int rc = dalloc(&D.Rv, (size_t)D.nnzP * 9)) return rc;
         if (int rc = dalloc(&D.Tv, (size_t)D.nnzT * 9)) return rc;
-        if (int rc = dalloc(&D.Ppm, (size_t)D.nnzP * 9)) return rc;
-        if (int rc = dalloc(&D.Rpm, (size_t)D.nnzP * 9)) return rc;
-        if (l == 0 && explicit0) { if (int rc = dalloc(&D.Apm, (size_t)D.nnzA * 9)) return rc; }
+        if (int rc = dalloc(&D.Ppm, (size_t)D.nnzP * cyw())) return rc;
+        if (int rc = dalloc(&D.Rpm, (size_t)D.nnzP * cyw())) return rc;
+        if (l == 0 && explicit0) { if (int rc = dalloc(&D.Apm, (size_t)D.nnzA * cyw())) return rc; }
         if (l > 0) {
-            if (int rc = dalloc(&D.Apm, (size_t)D.nnzA * 9)) return rc;
+            if (int rc = dalloc(&D.Apm, (size_t)D.nnzA * cyw())) return rc;
             if (int rc = dalloc(&D.r, (size_t)D.n * 3)) return rc;
             if (int rc = dalloc(&D.z, (size_t)D.n * 3)) return rc;
             if (int rc = dalloc(&D.res, (size_t)D.n * 3)) return rc;
@@ -442,7 +454,9 @@ template <typename T> struct Engine : IEngine {
     //   LM tables  : pair-plane-major [(zx, zy) | (w0, w1)] per slot, padding 0          (host/problem.h: lm_static)
     //   ODOM table : nine planes, rows 0-1 of the inverse measurement (6) + weights (3)
     //   state      : ps (x, y, cos, sin), theta, lmrec (lx, ly, 0 ...)
-    int stage_values(const tsgo_graph& g) {
+    // host_state: also refresh the layout's own copy of the estimates (pr.pose_xyt / lm_xy).  Only a refill does: on the first
+    // build build_problem has just stored the same values and the multigrid builder thread is reading them.
+    int stage_values(const tsgo_graph& g, bool host_state) {
         const size_t Sp = pr.by_pose.slots(), Sl = pr.by_lm.slots(), So = pr.odom.slots();
         const size_t P = (size_t)pr.P, L = (size_t)pr.L;
         const size_t o_p = 0, o_l = o_p + 4 * Sp, o_o = o_l + 4 * Sl, o_ps = o_o + 9 * So, o_th = o_ps + 4 * P, o_lm = o_th + P, total = o_lm + (size_t)kLmRec * std::max<size_t>(L, 1);
@@ -479,14 +493,14 @@ template <typename T> struct Engine : IEngine {
         if (bad_edge >= 0) return set_error(-2, "tsgo_set_graph: ODOM edge " + std::to_string(bad_edge) + " has a singular measurement matrix");
         for (size_t i = 0; i < P; ++i) {
             const double* v = g.v_pos + 3 * (size_t)pr.pose_vertex[i];
-            pr.pose_xyt[3 * i] = v[0]; pr.pose_xyt[3 * i + 1] = v[1]; pr.pose_xyt[3 * i + 2] = v[2];
+            if (host_state) { pr.pose_xyt[3 * i] = v[0]; pr.pose_xyt[3 * i + 1] = v[1]; pr.pose_xyt[3 * i + 2] = v[2]; }
             stage[o_ps + 4 * i] = (T)v[0]; stage[o_ps + 4 * i + 1] = (T)v[1]; stage[o_ps + 4 * i + 2] = (T)std::cos(v[2]); stage[o_ps + 4 * i + 3] = (T)std::sin(v[2]);
             stage[o_th + i] = (T)v[2];
         }
         std::fill(stage + o_lm, stage + o_lm + (size_t)kLmRec * std::max<size_t>(L, 1), T(0));
         for (size_t l = 0; l < L; ++l) {
             const double* v = g.v_pos + 3 * (size_t)pr.lm_vertex[l];
-            pr.lm_xy[2 * l] = v[0]; pr.lm_xy[2 * l + 1] = v[1];
+            if (host_state) { pr.lm_xy[2 * l] = v[0]; pr.lm_xy[2 * l + 1] = v[1]; }
             stage[o_lm + l * kLmRec] = (T)v[0]; stage[o_lm + l * kLmRec + 1] = (T)v[1];
         }
         auto put = [&](T* dst, size_t off, size_t n) -> int { if (n) HIP_OK(hipMemcpyAsync(dst, stage + off, n * sizeof(T), hipMemcpyHostToDevice, stream)); return 0; };
@@ -516,7 +530,17 @@ template <typename T> struct Engine : IEngine {
     // Same structure as the graph the tables were built for: refill values, keep everything else.
     int refill(const tsgo_graph& g) {
         const auto t0 = std::chrono::steady_clock::now();
-        if (int rc = stage_values(g)) { have_graph_data = false; return rc; }
+        const int rc = refill_values(g);
+        // any failure leaves tables, lever arms and solver state half-updated: the handle then holds no graph and the next
+        // tsgo_set_graph rebuilds from scratch
+        if (rc) { have_graph_data = false; return rc; }
+        ++structure_reuses;
+        ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        if (cfg.verbose || getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] set_graph: same structure as the previous graph: values refilled in %.1f ms\n", ms_setup);
+        return 0;
+    }
+    int refill_values(const tsgo_graph& g) {
+        if (int rc = stage_values(g, true)) return rc;
         if (amg_on) {           // the rigid-mode lever arms follow the new estimates (host/amg.h: refresh_amg_geometry)
             refresh_amg_geometry(pr.pose_xyt, amg);
             HIP_OK(hipStreamSynchronize(stream));
@@ -529,9 +553,6 @@ template <typename T> struct Engine : IEngine {
         }
         if (int rc = reset_solver_state()) return rc;
         HIP_OK(hipStreamSynchronize(stream));
-        ++structure_reuses;
-        ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (cfg.verbose || getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] set_graph: same structure as the previous graph: values refilled in %.1f ms\n", ms_setup);
         return 0;
     }
 
@@ -567,7 +588,7 @@ template <typename T> struct Engine : IEngine {
         if (int rc = alloc_table(tp, &st_p, pr.by_pose, 4, 4, true)) return rc;
         if (int rc = alloc_table(tl, &st_l, pr.by_lm, 4, 4, true)) return rc;
         if (int rc = alloc_table(to, &st_o, pr.odom, 9, oj() ? 6 : 3, false)) return rc;
-        if (int rc = stage_values(g)) return rc;
+        if (int rc = stage_values(g, false)) return rc;
         // table-kernel grids are multiples of 8 (one eighth of the slices per XCD, see xcd_block())
         nbP = 8 * (((tp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);
         nbL = 8 * (((tl.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);
@@ -614,6 +635,29 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
 
+    // ---- in-situ profiler (tsgo_profile_iteration): an event before every launch of an eagerly launched iteration ----
+    struct ProfMark { hipEvent_t e; char name[64]; char where[32]; double bytes; };
+    std::vector<ProfMark> prof; size_t prof_n = 0; bool prof_on = false;
+    static const char* tname() { return sizeof(T) == 8 ? "double" : "float"; }
+    // name: the kernel symbol as rocprofv3 prints it, without arguments (printf-style), e.g. "k_schur_lm<double, 4, 0, 1>"
+    // PF(...): the arguments (byte models, labels) are evaluated only while a profile is being taken
+#define PF(...) do { if (prof_on) pf(__VA_ARGS__); } while (0)
+    void pf(double bytes, const char* where, const char* fmt, ...) __attribute__((format(printf, 4, 5))) {
+        if (!prof_on) return;
+        if (prof_n == prof.size()) { ProfMark m{}; if (hipEventCreate(&m.e) != hipSuccess) { prof_on = false; return; } prof.push_back(m); }
+        ProfMark& m = prof[prof_n++];
+        va_list ap; va_start(ap, fmt); std::vsnprintf(m.name, sizeof(m.name), fmt, ap); va_end(ap);
+        std::snprintf(m.where, sizeof(m.where), "%s", where); m.bytes = bytes;
+        (void)hipEventRecord(m.e, stream);
+    }
+    std::string lvl(const char* role, size_t l) const { return std::string(role) + " L" + std::to_string(l); }
+    // algorithmic bytes of the table kernels and of the block-row kernels of the cycle
+    double od_slots_live() const { double od = 0; for (uint32_t e : pr.odom.edge) od += e != kNoEdge; return od; }     // profile / probes only
+    double bytes_schur_lm(bool low) const { const double s = low ? 4 : sizeof(T), v = sizeof(T); return (double)pr.n_lm_edges * (4 + 4 * s) + pr.P * 5.0 * v + pr.L * 5.0 * v; }
+    double bytes_schur_pose(bool low) const { const double s = low ? 4 : sizeof(T), v = sizeof(T); return (double)pr.n_lm_edges * (4 + 4 * s) + pr.L * 2.0 * v + pr.P * 14.0 * v + od_slots_live() * (4 + 6 * v); }
+    double bytes_sweep(const DevLevel<T>& L) const { return (double)L.nnzA * (4.0 * cyw() + 4) + (double)L.n * (3 * 3 * sizeof(T) + 9 * sizeof(H) + 4); }
+    double bytes_transfer(const DevLevel<T>& L, int vecs_fine) const { return (double)L.nnzP * (4.0 * cyw() + 4) + (double)L.n * 3 * sizeof(T) * vecs_fine + (double)L.n_agg * (3 * sizeof(T) + 4); }
+
     // ---- launches --------------------------------------------------------------------------------
     // damping of the current linearisation (rules = 1, graph_optimizer.py:24-43; 0 under the cpu/eigen rules) and the step the update takes
     double lambda = 0;
@@ -640,14 +684,19 @@ template <typename T> struct Engine : IEngine {
     // poses), so what lands in sbuf is a PARTIAL product and partial dots: one all-reduce of [3P | nbP] makes both whole
     // on every rank.  (r, z) partials are computed redundantly from replicated vectors and need no reduction.
     int launch_matvec(int slot, bool with_rz = false, bool low = false) {
+        const char* wh = low ? "in-cycle product" : (with_rz ? "PCG product" : "product");
         if (low) {
+            PF(bytes_schur_lm(true), wh, "k_schur_lm<%s, %d, 0, 1>", tname(), pr.by_lm.G);
             if (tl.n_slices > 0) LAUNCH_GML(pr.by_lm.G, k_schur_lm, 0, 1, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
+            PF(bytes_schur_pose(true), wh, "k_schur_pose<%s, %d, 1, %d>", tname(), pr.by_pose.G, oj() ? 1 : 0);
             if (oj()) LAUNCH_GML(pr.by_pose.G, k_schur_pose, 1, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
                                  (const T*)nullptr, rzpart);
             else LAUNCH_GML1(pr.by_pose.G, k_schur_pose, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
                              (const T*)nullptr, rzpart);
         } else {
+            PF(bytes_schur_lm(false), wh, "k_schur_lm<%s, %d, 0, 0>", tname(), pr.by_lm.G);
             if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
+            PF(bytes_schur_pose(false), wh, "k_schur_pose<%s, %d, 0, %d>", tname(), pr.by_pose.G, oj() ? 1 : 0);
             if (oj()) LAUNCH_GML(pr.by_pose.G, k_schur_pose, 0, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
                                  (const T*)(with_rz ? r : nullptr), rzpart);
             else LAUNCH_G(pr.by_pose.G, k_schur_pose, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
@@ -667,7 +716,7 @@ template <typename T> struct Engine : IEngine {
                            sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A, pr.rank == 0 ? 1 : 0,
                            to.idx, oj() ? 1 : 0);
         if (int rc = allreduce_h(L0.A, (size_t)L0.nnzA * 9)) return rc;
-        if (explicit0) hipLaunchKernelGGL((k_to_planes<T>), dim3(grid_for(L0.n, 8)), dim3(kBlock), 0, stream, L0.n, (const int*)L0.A_ptr, (const H*)L0.A, L0.Apm);
+        if (explicit0) do { if (cy16) hipLaunchKernelGGL((k_to_planes<T, 1>), dim3(grid_for(L0.n, 8)), dim3(kBlock), 0, stream, L0.n, (const int*)L0.A_ptr, (const H*)L0.A, L0.Apm); else hipLaunchKernelGGL((k_to_planes<T, 0>), dim3(grid_for(L0.n, 8)), dim3(kBlock), 0, stream, L0.n, (const int*)L0.A_ptr, (const H*)L0.A, L0.Apm); } while (0);
         for (size_t l = 0; l < lv.size(); ++l) {
             DevLevel<T>& L = lv[l];
             H* Anext = l + 1 < lv.size() ? lv[l + 1].A : A_last;
@@ -684,9 +733,9 @@ template <typename T> struct Engine : IEngine {
             else hipLaunchKernelGGL((k_pair_gemm<T, 1>), dim3(grid_for((L.n_upper + kPairBlocksPerWave - 1) / kPairBlocksPerWave, 64)), dim3(kBlock), 0, stream, L.n_upper, L.as_ptr, L.as_x, L.as_y, (const H*)L.P, (const H*)L.Tv, Anext, (const int*)L.as_upper);
             hipLaunchKernelGGL((k_mirror_blocks<T>), dim3(grid_for(L.nnzNext, 9)), dim3(kBlock), 0, stream, L.nnzNext, (const int*)L.as_mirror, Anext);
             // cycle format of what the V-cycle reads on this level (level 0's matrix is only read by the setup)
-            hipLaunchKernelGGL((k_to_planes<T>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, (const int*)L.P_ptr, (const H*)L.P, L.Ppm);
-            hipLaunchKernelGGL((k_to_planes<T>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, (const int*)L.R_ptr, (const H*)L.Rv, L.Rpm);
-            if (l + 1 < lv.size()) hipLaunchKernelGGL((k_to_planes<T>), dim3(grid_for(lv[l + 1].n, 8)), dim3(kBlock), 0, stream, lv[l + 1].n, (const int*)lv[l + 1].A_ptr, (const H*)lv[l + 1].A, lv[l + 1].Apm);
+            do { if (cy16) hipLaunchKernelGGL((k_to_planes<T, 1>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, (const int*)L.P_ptr, (const H*)L.P, L.Ppm); else hipLaunchKernelGGL((k_to_planes<T, 0>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, (const int*)L.P_ptr, (const H*)L.P, L.Ppm); } while (0);
+            do { if (cy16) hipLaunchKernelGGL((k_to_planes<T, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, (const int*)L.R_ptr, (const H*)L.Rv, L.Rpm); else hipLaunchKernelGGL((k_to_planes<T, 0>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, (const int*)L.R_ptr, (const H*)L.Rv, L.Rpm); } while (0);
+            if (l + 1 < lv.size()) do { if (cy16) hipLaunchKernelGGL((k_to_planes<T, 1>), dim3(grid_for(lv[l + 1].n, 8)), dim3(kBlock), 0, stream, lv[l + 1].n, (const int*)lv[l + 1].A_ptr, (const H*)lv[l + 1].A, lv[l + 1].Apm); else hipLaunchKernelGGL((k_to_planes<T, 0>), dim3(grid_for(lv[l + 1].n, 8)), dim3(kBlock), 0, stream, lv[l + 1].n, (const int*)lv[l + 1].A_ptr, (const H*)lv[l + 1].A, lv[l + 1].Apm); } while (0);
         }
         hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kDenseThreads), 0, stream, nb_last, last_ptr, last_col, (const H*)A_last, inv_last);
         return 0;
@@ -705,24 +754,38 @@ template <typename T> struct Engine : IEngine {
         if (n_rows >= 4096 && avg_row > 12) return 16;
         return lanes_for(avg_row);
     }
-#define LAUNCH_LPR(LPR, KERNEL, EXTRA, n_rows, ...)                                                                      \
+#define LAUNCH_LPR_(LPR, INST, n_rows, ...)                                                                              \
     do {                                                                                                                 \
         switch (LPR) {                                                                                                   \
-            case 4: hipLaunchKernelGGL((KERNEL<T, 4, EXTRA>), dim3(grid_for(n_rows, 4)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
-            case 8: hipLaunchKernelGGL((KERNEL<T, 8, EXTRA>), dim3(grid_for(n_rows, 8)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
-            case 16: hipLaunchKernelGGL((KERNEL<T, 16, EXTRA>), dim3(grid_for(n_rows, 16)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
-            case 32: hipLaunchKernelGGL((KERNEL<T, 32, EXTRA>), dim3(grid_for(n_rows, 32)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
-            default: hipLaunchKernelGGL((KERNEL<T, 64, EXTRA>), dim3(grid_for(n_rows, 64)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 4: hipLaunchKernelGGL((INST(4)), dim3(grid_for(n_rows, 4)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
+            case 8: hipLaunchKernelGGL((INST(8)), dim3(grid_for(n_rows, 8)), dim3(kBlock), 0, stream, __VA_ARGS__); break;   \
+            case 16: hipLaunchKernelGGL((INST(16)), dim3(grid_for(n_rows, 16)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            case 32: hipLaunchKernelGGL((INST(32)), dim3(grid_for(n_rows, 32)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
+            default: hipLaunchKernelGGL((INST(64)), dim3(grid_for(n_rows, 64)), dim3(kBlock), 0, stream, __VA_ARGS__); break; \
         }                                                                                                                \
     } while (0)
-    void launch_prolong(DevLevel<T>& L, const T* e, T* z, int zs, const CgState<T>* s) {
-        switch (lanes_for((double)L.nnzP / std::max(1, L.n))) {
-            case 4: hipLaunchKernelGGL((k_prolong_add<T, 4>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
-            case 8: hipLaunchKernelGGL((k_prolong_add<T, 8>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
-            case 16: hipLaunchKernelGGL((k_prolong_add<T, 16>), dim3(grid_for(L.n, 16)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
-            case 32: hipLaunchKernelGGL((k_prolong_add<T, 32>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
-            default: hipLaunchKernelGGL((k_prolong_add<T, 64>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.P_ptr, L.P_col, (const H*)L.Ppm, e, z, zs, s); break;
-        }
+    // a block-row sweep over the cycle-format copy of a level's matrix (MODE 0 residual, 1 smoothing sweep), f32 or packed half
+#define SWEEP_INST16(L_) k_bcsr_residual<T, L_, SWEEP_MODE, 1, 1>
+#define SWEEP_INST32(L_) k_bcsr_residual<T, L_, SWEEP_MODE, 1, 0>
+#define RESTRICT_INST16(L_) k_restrict<T, L_, SWEEP_MODE, 1>
+#define RESTRICT_INST32(L_) k_restrict<T, L_, SWEEP_MODE, 0>
+#define PROLONG_INST16(L_) k_prolong_add<T, L_, 1>
+#define PROLONG_INST32(L_) k_prolong_add<T, L_, 0>
+#define APPLY_INST16(L_) k_bcsr_apply<T, L_, 1>
+#define APPLY_INST32(L_) k_bcsr_apply<T, L_, 0>
+    template <int SWEEP_MODE> void launch_sweep(int lpr, DevLevel<T>& L, const T* rhs, const T* cur, T* out, const T* omega, const CgState<T>* s) {
+        if (cy16) LAUNCH_LPR_(lpr, SWEEP_INST16, L.n, L.n, L.A_ptr, L.A_col, (const void*)L.Apm, rhs, cur, (const H*)L.Dinv, out, omega, s);
+        else LAUNCH_LPR_(lpr, SWEEP_INST32, L.n, L.n, L.A_ptr, L.A_col, (const void*)L.Apm, rhs, cur, (const H*)L.Dinv, out, omega, s);
+    }
+    template <int SWEEP_MODE> void launch_restrict(int lpr, DevLevel<T>& L, const T* va, const T* vb, T* rc, const H* dinv_next, T* z_next, const T* omega, const CgState<T>* s) {
+        if (cy16) LAUNCH_LPR_(lpr, RESTRICT_INST16, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const uint32_t*)L.Rpm, va, vb, rc, dinv_next, z_next, omega, s);
+        else LAUNCH_LPR_(lpr, RESTRICT_INST32, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const uint32_t*)L.Rpm, va, vb, rc, dinv_next, z_next, omega, s);
+    }
+    void launch_prolong(DevLevel<T>& L, const T* e, T* z, int zs, const CgState<T>* s, size_t level) {
+        PF(bytes_transfer(L, 2), lvl("prolong into", level).c_str(), "k_prolong_add<%s, %d, %d>", tname(), lanes_for((double)L.nnzP / std::max(1, L.n)), cy16 ? 1 : 0);
+        const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n));
+        if (cy16) LAUNCH_LPR_(lpr, PROLONG_INST16, L.n, L.n, L.P_ptr, L.P_col, (const uint32_t*)L.Ppm, e, z, zs, s);
+        else LAUNCH_LPR_(lpr, PROLONG_INST32, L.n, L.n, L.P_ptr, L.P_col, (const uint32_t*)L.Ppm, e, z, zs, s);
     }
 
     // Damping of the block-Jacobi smoother per level from a power iteration on D^-1 A (12 steps): the V-cycle
@@ -738,11 +801,11 @@ template <typename T> struct Engine : IEngine {
             const int lprA = lanes_for((double)L.nnzA / std::max(1, L.n));
             for (int it = 0; it < kRhoSteps; ++it) {
                 switch (lprA) {     // the block-indexed matrix (PM = 0): level 0 has no cycle-format copy
-                    case 4: hipLaunchKernelGGL((k_bcsr_residual<T, 4, 2, 0>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
-                    case 16: hipLaunchKernelGGL((k_bcsr_residual<T, 16, 2, 0>), dim3(grid_for(L.n, 16)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
-                    case 8: hipLaunchKernelGGL((k_bcsr_residual<T, 8, 2, 0>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
-                    case 32: hipLaunchKernelGGL((k_bcsr_residual<T, 32, 2, 0>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
-                    default: hipLaunchKernelGGL((k_bcsr_residual<T, 64, 2, 0>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                    case 4: hipLaunchKernelGGL((k_bcsr_residual<T, 4, 2, 0>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const void*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                    case 16: hipLaunchKernelGGL((k_bcsr_residual<T, 16, 2, 0>), dim3(grid_for(L.n, 16)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const void*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                    case 8: hipLaunchKernelGGL((k_bcsr_residual<T, 8, 2, 0>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const void*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                    case 32: hipLaunchKernelGGL((k_bcsr_residual<T, 32, 2, 0>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const void*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
+                    default: hipLaunchKernelGGL((k_bcsr_residual<T, 64, 2, 0>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const void*)L.A, (const T*)a, (const T*)a, (const H*)L.Dinv, b, (const T*)omega_dev, (const CgState<T>*)st[0]); break;
                 }
                 std::swap(a, b);
             }
@@ -772,19 +835,16 @@ template <typename T> struct Engine : IEngine {
     // zc[.][0..2] = V(1,1)-cycle(r).  On entry zc already holds the level-0 pre-smoothing Minv r
     // (written by pose_finalize / k_cg_step).  Level l >= 1 keeps r, z (pre-smoothed by the restriction
     // above it), res and the post-smoothed result z2.
-    // research (TSGO_CYCLE_EXPLICIT0=1): the two products inside the cycle read the EXPLICIT level-0 matrix of the hierarchy
+    // tsgo_config.cycle_level0 = 1: the two products inside the cycle read the EXPLICIT level-0 matrix of the hierarchy
     // (lagged with it, hub landmarks truncated, f32) instead of the implicit Schur passes — no all-reduce in a sharded run
     bool explicit0 = false;
     int launch_cycle_product(int slot) {
         if (!explicit0) return launch_matvec(slot, false, low_cycle);
         DevLevel<T>& L = lv[0];
-        switch (lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n)) {
-            case 4: hipLaunchKernelGGL((k_bcsr_apply<T, 4>), dim3(grid_for(L.n, 4)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
-            case 8: hipLaunchKernelGGL((k_bcsr_apply<T, 8>), dim3(grid_for(L.n, 8)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
-            case 16: hipLaunchKernelGGL((k_bcsr_apply<T, 16>), dim3(grid_for(L.n, 16)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
-            case 32: hipLaunchKernelGGL((k_bcsr_apply<T, 32>), dim3(grid_for(L.n, 32)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
-            default: hipLaunchKernelGGL((k_bcsr_apply<T, 64>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]); break;
-        }
+        PF(bytes_sweep(L), "in-cycle product (explicit)", "k_bcsr_apply<%s, %d, %d>", tname(), lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n), cy16 ? 1 : 0);
+        const int lpr = lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n);
+        if (cy16) LAUNCH_LPR_(lpr, APPLY_INST16, L.n, L.n, L.A_ptr, L.A_col, (const uint32_t*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]);
+        else LAUNCH_LPR_(lpr, APPLY_INST32, L.n, L.n, L.A_ptr, L.A_col, (const uint32_t*)L.Apm, (const T*)zc, kPoseRec, sbuf, (const CgState<T>*)st[slot]);
         return 0;
     }
     int launch_vcycle(int slot) {
@@ -794,7 +854,8 @@ template <typename T> struct Engine : IEngine {
         {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-            if (nl > 1) LAUNCH_LPR(lpr, k_restrict, 1, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rpm, (const T*)r, (const T*)sbuf, lv[1].r, (const H*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
+            if (nl > 1) PF(bytes_transfer(L, 2), "restrict from L0", "k_restrict<%s, %d, 1, %d>", tname(), lpr, cy16 ? 1 : 0);
+            if (nl > 1) launch_restrict<1>(lpr, L, (const T*)r, (const T*)sbuf, lv[1].r, (const H*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
         }
         // coarse levels: V(nu,nu) with nu = coarse_sweeps block-Jacobi sweeps (the first pre-sweep comes fused
         // with the restriction above).  The current iterate alternates between L.z and L.z2; it ends in L.z2.
@@ -804,13 +865,16 @@ template <typename T> struct Engine : IEngine {
             const int lprA = lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n);
             T* cur = L.z; T* oth = L.z2;
             for (int sw = 1; sw < nu; ++sw) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, oth, (const T*)(omega_dev + l), s);
+                PF(bytes_sweep(L), lvl("pre-sweep", l).c_str(), "k_bcsr_residual<%s, %d, 1, 1, %d>", tname(), lprA, cy16 ? 1 : 0);
+                launch_sweep<1>(lprA, L, (const T*)L.r, (const T*)cur, oth, (const T*)(omega_dev + l), s);
                 std::swap(cur, oth);
             }
-            LAUNCH_LPR(lprA, k_bcsr_residual, 0, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, L.res, (const T*)(omega_dev + l), s);
+            PF(bytes_sweep(L), lvl("residual", l).c_str(), "k_bcsr_residual<%s, %d, 0, 1, %d>", tname(), lprA, cy16 ? 1 : 0);
+            launch_sweep<0>(lprA, L, (const T*)L.r, (const T*)cur, L.res, (const T*)(omega_dev + l), s);
             if (l + 1 < nl) {
                 const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-                LAUNCH_LPR(lpr, k_restrict, 0, L.n_agg, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rpm, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const H*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
+                PF(bytes_transfer(L, 1), lvl("restrict from", l).c_str(), "k_restrict<%s, %d, 0, %d>", tname(), lpr, cy16 ? 1 : 0);
+                launch_restrict<0>(lpr, L, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const H*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
             }
         }
         // iterate of level l after the down pass: L.z when nu is odd, L.z2 when even
@@ -818,45 +882,54 @@ template <typename T> struct Engine : IEngine {
         auto down_other = [&](DevLevel<T>& L, int nu) { return (nu % 2) ? L.z2 : L.z; };
         if (nl > 1 && lv[nl - 1].n * 4 <= kDenseThreads) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
             DevLevel<T>& L = lv[nl - 1];
+            PF(2.0 * L.nnzP * (9 * sizeof(H) + 4) + (double)nb_last * 3 * nb_last * 3 * sizeof(T) + L.n * 6.0 * sizeof(T), lvl("restrict + dense solve + prolong", nl - 1).c_str(), "k_coarse_tail<%s>", tname());
             hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kDenseThreads), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv, L.P_ptr, L.P_col, (const H*)L.P,
                                (const T*)L.res, (const T*)inv_last, down_iter(L, nu_at(nl - 1)), s);
         } else if (nl > 1) {   // a last explicit level too long for the one-workgroup kernel (4 lanes per row): the same three steps as launches
             DevLevel<T>& L = lv[nl - 1];
-            hipLaunchKernelGGL((k_restrict<T, 8, 0>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rpm,
-                               (const T*)L.res, (const T*)L.res, r_last, (const H*)nullptr, (T*)nullptr, (const T*)one_dev, s);
+            PF(bytes_transfer(L, 1), lvl("restrict from", nl - 1).c_str(), "k_restrict<%s, 8, 0, %d>", tname(), cy16 ? 1 : 0);
+            launch_restrict<0>(8, L, (const T*)L.res, (const T*)L.res, r_last, (const H*)nullptr, (T*)nullptr, (const T*)one_dev, s);
+            PF((double)nb_last * 3 * nb_last * 3 * sizeof(T), "dense solve", "k_dense_apply<%s>", tname());
             hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
-            launch_prolong(L, z_last, down_iter(L, nu_at(nl - 1)), 3, s);
+            launch_prolong(L, z_last, down_iter(L, nu_at(nl - 1)), 3, s, nl - 1);
         } else {        // only level 0 above the dense level: residual r - S z is restricted from (r, sbuf)
             DevLevel<T>& L = lv[0];
-            hipLaunchKernelGGL((k_restrict<T, 8, 1>), dim3(grid_for(L.n_agg, 8)), dim3(kBlock), 0, stream, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rpm,
-                               (const T*)r, (const T*)sbuf, r_last, (const H*)nullptr, (T*)nullptr, (const T*)one_dev, s);
+            PF(bytes_transfer(L, 2), "restrict from L0", "k_restrict<%s, 8, 1, %d>", tname(), cy16 ? 1 : 0);
+            launch_restrict<1>(8, L, (const T*)r, (const T*)sbuf, r_last, (const H*)nullptr, (T*)nullptr, (const T*)one_dev, s);
+            PF((double)nb_last * 3 * nb_last * 3 * sizeof(T), "dense solve", "k_dense_apply<%s>", tname());
             hipLaunchKernelGGL((k_dense_apply<T>), dim3(1), dim3(kBlock), 0, stream, nb_last * 3, (const T*)inv_last, (const T*)r_last, z_last, s);
         }
         for (size_t l = nl - 1; l >= 1; --l) {
             DevLevel<T>& L = lv[l];
             const int nu = nu_at(l);
             T* cur = down_iter(L, nu); T* oth = down_other(L, nu);
-            if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, cur, 3, s);
+            if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, cur, 3, s, l);
             const int lprA = lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n);
             for (int sw = 0; sw < nu; ++sw) {
-                LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)L.r, (const T*)cur, (const H*)L.Dinv, oth, (const T*)(omega_dev + l), s);
+                PF(bytes_sweep(L), lvl("post-sweep", l).c_str(), "k_bcsr_residual<%s, %d, 1, 1, %d>", tname(), lprA, cy16 ? 1 : 0);
+                launch_sweep<1>(lprA, L, (const T*)L.r, (const T*)cur, oth, (const T*)(omega_dev + l), s);
                 std::swap(cur, oth);
             }
             // nu post-sweeps after nu-1 pre-swaps: the result sits in L.z2 for every nu (odd+odd / even+even swaps)
         }
-        launch_prolong(lv[0], nl > 1 ? (const T*)lv[1].z2 : (const T*)z_last, zc, kPoseRec, s);
+        launch_prolong(lv[0], nl > 1 ? (const T*)lv[1].z2 : (const T*)z_last, zc, kPoseRec, s, 0);
         if (int rc = launch_cycle_product(slot)) return rc;
+        PF(pr.P * (6 + 3 + 3 + 3 + 3) * (double)sizeof(T), "post-smoothing L0", "k_smooth0<%s, 1>", tname());
         hipLaunchKernelGGL((k_smooth0<T, 1>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, (const T*)sbuf, zc, (const T*)omega_dev, s);
         return 0;
     }
     void launch_cg_step(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
+        PF(pr.P * (3 + 3 + 6 + 4 * 3 * 2) * (double)sizeof(T), "vector step + pre-smoothing L0", "k_cg_step<%s>", tname());
         hipLaunchKernelGGL((k_cg_step<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)(sbuf + (size_t)pr.P * 3), (const T*)rzpart, nbP,
-                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, (const T*)omega_dev, tol2, cfg.pcg_max_iters, (const T*)gscale_dev, kAmgStallIter, (T)kAmgStallRatio);
+                           (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, (const T*)omega_dev, tol2, cfg.pcg_max_iters, (const T*)gscale_dev, kAmgStallIter, (T)kAmgStallRatio,
+                           npart);
     }
     // one PCG iteration reading state slot `slot`, writing slot^1
     int launch_iteration(int slot) {
         if (amg_on) {
+            PF(2.0 * nbC * sizeof(T), "stopping rule", "k_iter_gate<%s>", tname());
+            hipLaunchKernelGGL((k_iter_gate<T>), dim3(1), dim3(kBlock), 0, stream, st[slot], (const T*)npart, (const T*)gpart[0], nbC, (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol));
             if (int rc = launch_vcycle(slot)) return rc;
             if (int rc = launch_matvec(slot, true)) return rc;
             launch_cg_step(slot);
@@ -872,6 +945,7 @@ template <typename T> struct Engine : IEngine {
     }
     void launch_cg_update(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);
+        PF(pr.P * (3 + 3 + 6 + 4 * 3 * 2) * (double)sizeof(T), "vector step", "k_cg_update<%s>", tname());
         hipLaunchKernelGGL((k_cg_update<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, sbuf, sbuf + (size_t)pr.P * 3, nbP, gpart[slot], nbC,
                            gpart[slot ^ 1], st[slot], st[slot ^ 1], minv, r, p, q, x, zc, tol2, cfg.pcg_max_iters, (const T*)gscale_dev);
     }
@@ -965,24 +1039,13 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, a, (const T*)nullptr, T(0));
         if (int rc = launch_matvec(0)) return rc;
         hipLaunchKernelGGL((k_warm_residual<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)minv, r, zc, (const T*)(amg_on ? omega_dev : one_dev), npart);
-        hipLaunchKernelGGL((k_warm_scale<T>), dim3(1), dim3(kBlock), 0, stream, nbC, (const T*)gpart[0], (const T*)npart, amg_on ? (T*)nullptr : gpart[0], gscale_dev);
+        hipLaunchKernelGGL((k_warm_scale<T>), dim3(1), dim3(kBlock), 0, stream, nbC, (const T*)gpart[0], (const T*)npart, amg_on ? (T*)nullptr : gpart[0], gscale_dev,
+                           amg_on ? st[0] : (CgState<T>*)nullptr, (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol));
         return 0;
-    }
-    // certify a multigrid-preconditioned solve in a norm the multigrid operator has no part in: r^T D^-1 r against
-    // b^T D^-1 b (partials left by k_pose_finalize in gpart[0]).  An indefinite preconditioner can make r^T M^-1 r small
-    // while r is not.  (k_resid_norm ran and its partials came back with the device state: do_solve_once.)
-    void certify(const int* iters, int* fail) {
-        if (*fail != 0 || !amg_on) return;
-        double num = 0, den = 0;
-        for (int k = 0; k < nbC; ++k) { num += (double)h_scratch[k]; den += (double)h_scratch[nbC + k]; }
-        const double lim = kCertifySlack * cfg.pcg_rel_tol;
-        if (getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] certificate: sqrt(rDr/bDb) = %.3e (tol %.1e, limit %.1e), %d iterations\n", std::sqrt(num / den), cfg.pcg_rel_tol, lim, *iters);
-        if (!(num <= lim * lim * den)) *fail = 1;
     }
     int do_solve(int* iters, int* fail) {
         if (cfg.warm_start && have_prev) { if (int rc = launch_warm()) return rc; }
         if (int rc = do_solve_once(iters, fail)) return rc;
-        certify(iters, fail);
         if (*fail == 3 && amg_on) *fail = 1;          // stagnation under the multigrid cycle
         const int age_used = hier_age;
         if (amg_on) { iters_last = *iters; if (hier_age == 0) iters_fresh = *iters; if (hier_age >= 0) ++hier_age; }
@@ -996,7 +1059,6 @@ template <typename T> struct Engine : IEngine {
             hier_age = 0;
             launch_finalize();
             if (int rc = do_solve_once(iters, fail)) return rc;
-            certify(iters, fail);
             if (*fail == 3) *fail = 1;
             iters_last = *iters; iters_fresh = *iters; hier_age = 1;
         }
@@ -1034,12 +1096,6 @@ template <typename T> struct Engine : IEngine {
             }
             if (timing) std::fprintf(stderr, "[tsgo] solve: %d chunk(s) enqueued at %.0f us", burst, since());
             burst = 1;
-            // the residual certificate (do_solve) rides on the same round trip: its 7 us are wasted only when the look is too early
-            if (amg_on) {
-                hipLaunchKernelGGL((k_resid_norm<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)minv, (const T*)r, npart);
-                HIP_OK(hipMemcpyAsync(h_scratch, npart, sizeof(T) * nbC, hipMemcpyDeviceToHost, stream));
-                HIP_OK(hipMemcpyAsync(h_scratch + nbC, gpart[0], sizeof(T) * nbC, hipMemcpyDeviceToHost, stream));
-            }
             HIP_OK(hipMemcpyAsync(h_state, st[0], sizeof(CgState<T>), hipMemcpyDeviceToHost, stream));
             HIP_OK(hipStreamSynchronize(stream));
             if (timing) std::fprintf(stderr, ", drained at %.0f us (iters %d done %d)\n", since(), h_state->iters, h_state->done);
@@ -1241,15 +1297,59 @@ template <typename T> struct Engine : IEngine {
                 const int m = pass == 0 ? 3 : reps;
                 HIP_OK(hipEventRecord(ev[0], stream));
                 for (int k = 0; k < m; ++k)
-                    LAUNCH_LPR(lprA, k_bcsr_residual, 1, L.n, L.n, L.A_ptr, L.A_col, (const H*)L.Apm, (const T*)L.r, (const T*)L.z, (const H*)L.Dinv, L.z2, (const T*)(omega_dev + l), (const CgState<T>*)st[0]);
+                    launch_sweep<1>(lprA, L, (const T*)L.r, (const T*)L.z, L.z2, (const T*)(omega_dev + l), (const CgState<T>*)st[0]);
                 HIP_OK(hipEventRecord(ev[1], stream));
                 HIP_OK(hipEventSynchronize(ev[1]));
                 if (pass == 1) { float ms = 0; HIP_OK(hipEventElapsedTime(&ms, ev[0], ev[1])); out[n].us_per_sweep = 1e3 * ms / m; }
             }
             out[n].rows = L.n; out[n].blocks = L.nnzA; out[n].lanes_per_row = lprA;
             out[n].sweeps_per_cycle = 2 * nu_at(l);         // (nu - 1) pre-sweeps + the residual + nu post-sweeps
-            out[n].bytes_per_sweep = (double)L.nnzA * (9 * sizeof(H) + 4) + (double)L.n * (3 * 3 * sizeof(T) + 9 * sizeof(H) + 4);
+            out[n].bytes_per_sweep = bytes_sweep(L);
         }
+        return n;
+    }
+
+    // One PCG iteration kernel by kernel, in situ: `reps` iterations launched eagerly, the stopping test disabled, an event before
+    // every launch (PF()).  Entry k of the result = the k-th launch of an iteration, averaged over the iterations.
+    int profile_iteration(int reps, tsgo_prof_entry* out, int cap) override {
+        if (!have_graph_data) return set_error(-3, "tsgo_profile_iteration: no graph set");
+        HIP_OK(hipSetDevice(cfg.device));
+        double chi2;
+        if (int rc = do_linearize(&chi2)) return rc;      // valid operands, a built hierarchy; state slot 0 says "not done"
+        struct TolGuard { double& tol; double keep; ~TolGuard() { tol = keep; } } tol_guard{cfg.pcg_rel_tol, cfg.pcg_rel_tol};
+        cfg.pcg_rel_tol = 0;
+        reps = std::max(2, reps + (reps & 1));           // whole pairs: the state ring has two slots
+        for (int j = 0; j < 4; ++j) if (int rc = launch_iteration(j & 1)) return rc;        // warm caches and clocks
+        // Eager launches + event records are host-bound (~7 us each against kernels of 4-15 us): the stream is first blocked by a
+        // kernel that waits kProfBlockMs on the constant-rate clock, the host enqueues everything behind it, and the device then
+        // runs the queue back to back — what a hipGraph replay of the same iterations does.
+        hipLaunchKernelGGL(k_wait_ms, dim3(1), dim3(64), 0, stream, (int)(kProfBlockUsPerLaunch * 40.0 * reps / 1000.0) + 2);
+        prof_n = 0; prof_on = true;
+        int rc = 0;
+        for (int j = 0; j < reps && rc == 0; ++j) rc = launch_iteration(j & 1);
+        PF(0, "", "end");
+        prof_on = false;
+        HIP_OK(hipStreamSynchronize(stream));
+        if (rc) return rc;
+        const size_t marks = prof_n - 1;
+        if (marks == 0 || marks % (size_t)reps != 0) return set_error(-30, "tsgo_profile_iteration: the iterations did not launch the same kernels");
+        const size_t per = marks / (size_t)reps;
+        const int n = (int)std::min<size_t>(per, (size_t)cap);
+        for (int k = 0; k < n; ++k) {
+            double sum = 0;
+            for (int j = 0; j < reps; ++j) {
+                float ms = 0;
+                HIP_OK(hipEventElapsedTime(&ms, prof[(size_t)j * per + k].e, prof[(size_t)j * per + k + 1].e));
+                sum += ms;
+            }
+            const ProfMark& m = prof[k];
+            std::memset(&out[k], 0, sizeof(out[k]));
+            std::snprintf(out[k].name, sizeof(out[k].name), "%s", m.name);
+            std::snprintf(out[k].where, sizeof(out[k].where), "%s", m.where);
+            out[k].launches_per_iteration = 1; out[k].us = 1e3 * sum / reps; out[k].bytes = m.bytes;
+        }
+        cfg.pcg_rel_tol = tol_guard.keep;
+        if (int rc2 = do_linearize(&chi2)) return rc2;   // leave a consistent state behind
         return n;
     }
 
@@ -1373,6 +1473,10 @@ int tsgo_time_kernel(tsgo_optimizer* o, int32_t which, int32_t reps, double* us,
 int tsgo_cycle_probe(tsgo_optimizer* o, int32_t reps, tsgo_cycle_level* out, int32_t cap) {
     if (!o || !out || reps <= 0 || cap <= 0) return tsgo::set_error(-1, "tsgo_cycle_probe: bad argument");
     return o->eng->cycle_probe(reps, out, cap);
+}
+int tsgo_profile_iteration(tsgo_optimizer* o, int32_t reps, tsgo_prof_entry* out, int32_t cap) {
+    if (!o || !out || reps <= 0 || cap <= 0) return tsgo::set_error(-1, "tsgo_profile_iteration: bad argument");
+    return o->eng->profile_iteration(reps, out, cap);
 }
 int tsgo_local_group_create(int32_t world, tsgo_local_group** out) {
     if (!out || world < 1) return tsgo::set_error(-1, "tsgo_local_group_create: bad argument");

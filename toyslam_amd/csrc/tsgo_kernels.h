@@ -578,14 +578,20 @@ __global__ __launch_bounds__(kBlock) void k_warm_residual(int P, const T* __rest
 }
 
 // scale = max(1, (b^T D^-1 b) / (r0^T D^-1 r0)) from the two partial arrays; one workgroup.
+// st0 (multigrid PCG, whose stopping rule is r^T D^-1 r <= tol^2 b^T D^-1 b, k_cg_step): a warm start that already meets the
+// rule ends the solve before its first iteration.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_warm_scale(int n, const T* b_part, const T* __restrict__ r_part, T* gpart_out, T* __restrict__ scale) {
+__global__ __launch_bounds__(kBlock) void k_warm_scale(int n, const T* b_part, const T* __restrict__ r_part, T* gpart_out, T* __restrict__ scale,
+                                                       CgState<T>* __restrict__ st0, T tol2) {
     __shared__ T red[kWavesPerBlock];
     const T nb = block_sum_array<T>(b_part, n, red);
     const T nr = block_sum_array<T>(r_part, n, red);
     // block-Jacobi PCG reads gamma = r^T Minv r from gpart: hand it the warm-started value
     if (gpart_out) for (int k = threadIdx.x; k < n; k += kBlock) gpart_out[k] = r_part[k];
-    if (threadIdx.x == 0) *scale = (nr > T(0) && nb > nr) ? nb / nr : T(1);
+    if (threadIdx.x == 0) {
+        *scale = (nr > T(0) && nb > nr) ? nb / nr : T(1);
+        if (st0 && !(nr > tol2 * nb)) st0->done = 1;
+    }
 }
 
 // pose (+)= step * delta: VertexSe2::Update (remote/graph/vertex/VertexSe2.h:16-27) with the 0.2 of

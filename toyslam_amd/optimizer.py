@@ -17,7 +17,7 @@ STOP = {0: "cap", 1: "worse", 2: "plateau", 3: "converged", 4: "solver_failed"}
 class HipOptimizer:
     def __init__(self, device=0, precision=64, pcg_rel_tol=1e-10, pcg_max_iters=20000, lanes_per_pose=0,
                  lanes_per_lm=0, use_graphs=True, rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None,
-                 reuse_structure=None, rules="cpp", lr=0.2, odom_jacobian="constant"):
+                 reuse_structure=None, rules="cpp", lr=0.2, odom_jacobian="constant", cycle_level0="implicit", cycle_storage=16):
         self.lib = _lib.hip_lib()
         cfg = _lib.tsgo_config()
         self.lib.tsgo_default_config(C.byref(cfg))
@@ -33,6 +33,8 @@ class HipOptimizer:
             cfg.reuse_structure = int(reuse_structure)
         cfg.rules, cfg.lr = {"cpp": 0, "python": 1}[rules], float(lr)
         cfg.odom_jacobian = {"constant": 0, "analytic": 1}[odom_jacobian]
+        cfg.cycle_level0 = {"implicit": 0, "explicit": 1}[cycle_level0]
+        cfg.cycle_storage = {16: 16, 32: 32}[cycle_storage]
         self.cfg = cfg
         self.h = C.c_void_p()
         _lib.check(self.lib, self.lib.tsgo_create(C.byref(cfg), C.byref(self.h)), "tsgo_create")
@@ -95,6 +97,14 @@ class HipOptimizer:
         n = self.lib.tsgo_cycle_probe(self.h, reps, arr, 16)
         _lib.check(self.lib, min(n, 0), "tsgo_cycle_probe")
         return [(arr[k].us_per_sweep, arr[k].bytes_per_sweep, arr[k].sweeps_per_cycle) for k in range(n)]
+
+    def profile_iteration(self, reps=20):
+        """In-situ per-kernel timing of one PCG iteration: list of dict(name, where, launches, us, bytes) in launch order."""
+        arr = (_lib.tsgo_prof_entry * 128)()
+        n = self.lib.tsgo_profile_iteration(self.h, reps, arr, 128)
+        _lib.check(self.lib, min(n, 0), "tsgo_profile_iteration")
+        return [dict(name=arr[k].name.decode(), where=arr[k].where.decode(), launches=arr[k].launches_per_iteration, us=arr[k].us, bytes=arr[k].bytes)
+                for k in range(n)]
 
     def comm_init_local(self, group):
         """group: a handle from local_group(world) shared by the handles of this process (one thread each)."""

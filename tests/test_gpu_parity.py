@@ -467,10 +467,11 @@ def test_c3_one_full_size_step_matches_the_cpu_twin():
     assert r["cg_iters"] < 150
 
 
-def test_multigrid_breakdown_falls_back_to_block_jacobi(monkeypatch):
-    """Aggregates of 4 on the coarse levels make the hierarchy indefinite on this graph (seen on the CPU twin
-    and on the device): the device flags r^T M^-1 r < 0 / fails the residual certificate and the solve is
-    repeated with block-Jacobi.  Same answer either way."""
+def test_aggregates_of_four_on_every_level_still_give_the_same_answer(monkeypatch):
+    """Aggregates of 4 on the coarse levels (research knob TSGO_AGGC) give a much weaker hierarchy on this graph — under round
+    1's fixed smoother damping an indefinite one.  Whatever the preconditioner does, the stopping rule measures the residual
+    itself (r^T D^-1 r), so the answer is the block-Jacobi run's.  Whether a solve had to be repeated with block-Jacobi is
+    reported, not required: the fallback path itself is pinned by test_gauge_free_graph_on_the_device (fallbacks >= 1)."""
     g = synth.make(20000, 10, seed=2)
     o = HipOptimizer(pcg_rel_tol=1e-10, preconditioner="jacobi")
     try:
@@ -485,7 +486,7 @@ def test_multigrid_breakdown_falls_back_to_block_jacobi(monkeypatch):
         o.close()
     np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9)
     assert util.max_vertex_diff(v, vref, g.v_type) < 1e-7
-    assert r["fallbacks"] >= 1            # the indefinite hierarchy was met and the block-Jacobi repeat answered
+    print("aggregates of 4: PCG iterations %s, solves repeated with block-Jacobi: %d" % (list(r["cg_iters"]), r["fallbacks"]))
 
 
 @pytest.mark.parametrize("name", sorted(edge_cases.CASES))

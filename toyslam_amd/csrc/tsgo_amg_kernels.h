@@ -354,6 +354,9 @@ __global__ __launch_bounds__(kBlock) void k_to_planes(int n_rows, const int* __r
 }
 
 // ---- V-cycle ---------------------------------------------------------------------------------------
+// Early exit of a finished solve: every cycle kernel reads st->done.  The flag is REQUESTED first and TESTED only after the loads that
+// depend on the kernel arguments alone (row bounds, the row's own entries) have been issued: tested at the very top it put one
+// more scalar round trip (st -> done) in front of the first vector load of kernels whose whole life is four such trips.
 // The coarse levels hold little work (12.5k / 1.5k / 196 block rows at 100k poses): what matters is the
 // length of the dependent-load chain, so LPR lanes share one block row (one 3x3 block per lane per
 // trip, 72 contiguous bytes per lane) and finish with an LPR-lane xor-shuffle sum.
@@ -366,12 +369,15 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
                                                           const void* __restrict__ Av, const T* __restrict__ r, const T* __restrict__ z,
                                                           const HT<T>* __restrict__ Dinv, T* __restrict__ out,
                                                           const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
-    if (MODE != 2 && st->done) return;
+    const int done = MODE != 2 ? st->done : 0;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     // LPR == 64: the row is wave-uniform, its bounds come through the scalar cache (one dependent round trip shorter)
     const int i = LPR == 64 ? __builtin_amdgcn_readfirstlane(g < n ? g : n - 1) : (g < n ? g : n - 1);
     T s0 = 0, s1 = 0, s2 = 0;
-    const int p0 = ptr[i], p1 = ptr[i + 1];
+    int p0 = ptr[i];
+    const int p1 = ptr[i + 1];
+    issue_before_exit(p0);
+    if (done) return;
     // What the row's epilogue needs (its right-hand side, its own entry of z, its diagonal inverse) depends on the row
     // alone: requested now, it arrives while the blocks are walked instead of adding a fourth dependent trip at the end.
     const bool head = g < n && sub == 0;
@@ -422,11 +428,14 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
 template <typename T, int LPR, int PK>
 __global__ __launch_bounds__(kBlock) void k_bcsr_apply(int n, const int* __restrict__ ptr, const int* __restrict__ col, const uint32_t* __restrict__ A,
                                                        const T* __restrict__ z, int zs, T* __restrict__ out, const CgState<T>* __restrict__ st) {
-    if (st->done) return;
+    const int done = st->done;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
-    const int p0 = ptr[i], p1 = ptr[i + 1];
+    int p0 = ptr[i];
+    const int p1 = ptr[i + 1];
+    issue_before_exit(p0);
+    if (done) return;
     const size_t len = (size_t)(p1 - p0);
     const uint32_t* base = A + (size_t)p0 * cy_words<PK>();
     for (int a = p0 + sub; a < p1; a += LPR) {
@@ -447,11 +456,14 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
                                                      const uint32_t* __restrict__ Rv, const T* __restrict__ va,
                                                      const T* __restrict__ vb, T* __restrict__ rc, const HT<T>* __restrict__ dinv_next,
                                                      T* __restrict__ z_next, const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
-    if (st->done) return;
+    const int done = st->done;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int a = g < n_agg ? g : n_agg - 1;
     T s0 = 0, s1 = 0, s2 = 0;
-    const int p0 = rptr[a], p1 = rptr[a + 1];
+    int p0 = rptr[a];
+    const int p1 = rptr[a + 1];
+    issue_before_exit(p0);
+    if (done) return;
     const bool head = g < n_agg && sub == 0;
     HT<T> dn[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // the next level's diagonal inverse: asked for before the walk, used after it
     T omega = 0;
@@ -485,12 +497,15 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
 template <typename T, int LPR, int PK = 0>
 __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __restrict__ pptr, const int* __restrict__ pcol,
                                                         const uint32_t* __restrict__ P, const T* __restrict__ e, T* __restrict__ z, int zs,
-                                                        const CgState<T>* __restrict__ st) {
-    if (st->done) return;
+                                                        const CgState<T>* __restrict__ st, float* __restrict__ z32 = nullptr) {
+    const int done = st->done;
     const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
-    const int p0 = pptr[i], p1 = pptr[i + 1];
+    int p0 = pptr[i];
+    const int p1 = pptr[i + 1];
+    issue_before_exit(p0);
+    if (done) return;
     const bool head = g < n && sub == 0;
     T z0 = 0, z1 = 0, z2 = 0;                          // the entry this row adds to: read before the walk
     if (head) { z0 = z[(size_t)i * zs]; z1 = z[(size_t)i * zs + 1]; z2 = z[(size_t)i * zs + 2]; }
@@ -504,7 +519,10 @@ __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __rest
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
     s0 = group_sum<T, LPR>(s0); s1 = group_sum<T, LPR>(s1); s2 = group_sum<T, LPR>(s2);
-    if (head) { z[(size_t)i * zs] = z0 + s0; z[(size_t)i * zs + 1] = z1 + s1; z[(size_t)i * zs + 2] = z2 + s2; }
+    if (head) {
+        z[(size_t)i * zs] = z0 + s0; z[(size_t)i * zs + 1] = z1 + s1; z[(size_t)i * zs + 2] = z2 + s2;
+        if (z32) { float* q = z32 + (size_t)i * zs; q[0] = (float)(z0 + s0); q[1] = (float)(z1 + s1); q[2] = (float)(z2 + s2); }     // level 0: the pose records' f32 copy
+    }
 }
 
 // Bottom of the V-cycle in ONE workgroup of 1024 threads: restrict the last explicit level's residual
@@ -515,13 +533,18 @@ __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg,
                                                                const HT<T>* __restrict__ Rv, const int* __restrict__ pptr,
                                                                const int* __restrict__ pcol, const HT<T>* __restrict__ P, const T* __restrict__ res,
                                                                const T* __restrict__ inv, T* __restrict__ z, const CgState<T>* __restrict__ st) {
-    if (st->done) return;
+    const int done = st->done;
     __shared__ T rc[kDenseMax], zc_[kDenseMax];
     {
         const int a = threadIdx.x / 32, sub = threadIdx.x % 32;
         T s0 = 0, s1 = 0, s2 = 0;
+        const int ac = a < n_agg ? a : n_agg - 1;
+        int rb0 = rptr[ac];
+        const int rb1 = rptr[ac + 1];
+        issue_before_exit(rb0);
+        if (done) return;
         if (a < n_agg)
-            for (int rb = rptr[a] + sub; rb < rptr[a + 1]; rb += 32) {
+            for (int rb = rb0 + sub; rb < rb1; rb += 32) {
                 const HT<T>* b = Rv + (size_t)rb * 9; const size_t i = (size_t)rcol[rb] * 3;
                 const T x0 = res[i], x1 = res[i + 1], x2 = res[i + 2];
                 s0 += b[0] * x0 + b[1] * x1 + b[2] * x2; s1 += b[3] * x0 + b[4] * x1 + b[5] * x2; s2 += b[6] * x0 + b[7] * x1 + b[8] * x2;
@@ -564,10 +587,12 @@ __global__ __launch_bounds__(kBlock) void k_dense_apply(int n, const T* __restri
 template <typename T, int MODE>
 __global__ __launch_bounds__(kBlock) void k_smooth0(int P, const T* __restrict__ minv, const T* __restrict__ r, const T* __restrict__ s,
                                                     T* __restrict__ zc, const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
-    if (st->done) return;
+    const int done = st->done;
     const int i = blockIdx.x * kBlock + threadIdx.x;
     if (i >= P) return;
     T e0 = r[(size_t)i * 3], e1 = r[(size_t)i * 3 + 1], e2 = r[(size_t)i * 3 + 2];
+    issue_before_exit(e0);
+    if (done) return;
     if (MODE == 1) { e0 -= s[(size_t)i * 3]; e1 -= s[(size_t)i * 3 + 1]; e2 -= s[(size_t)i * 3 + 2]; }
     T z0, z1, z2;
     sym3_mul<T>(minv + (size_t)i * 6, e0, e1, e2, z0, z1, z2);
@@ -608,7 +633,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
                                                     T* __restrict__ q, T* __restrict__ x, T* __restrict__ zc,
                                                     const T* __restrict__ minv, const T* __restrict__ omega_ptr, T tol2, int max_iters,
                                                     const T* __restrict__ gamma0_scale, int stall_iter, T stall_ratio,
-                                                    T* __restrict__ rdr_part) {
+                                                    T* __restrict__ rdr_part, float* __restrict__ zc32) {
     __shared__ T red[kWavesPerBlock];
     const CgState<T> s = *st_in;
     const bool writer = blockIdx.x == 0 && threadIdx.x == 0;
@@ -647,6 +672,7 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
         const T w = *omega_ptr;
         T* zr = zc + (size_t)i * kPoseRec;
         zr[0] = w * z0; zr[1] = w * z1; zr[2] = w * z2;
+        if (zc32) { float* zq = zc32 + (size_t)i * kPoseRec; zq[0] = (float)(w * z0); zq[1] = (float)(w * z1); zq[2] = (float)(w * z2); }
         g = rr[0] * z0 + rr[1] * z1 + rr[2] * z2;
     }
     const T total = block_sum<T>(g, red);
@@ -659,9 +685,13 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_iter_gate(CgState<T>* __restrict__ st, const T* __restrict__ rdr_part, const T* __restrict__ bpart, int n, T tol2) {
     __shared__ T red[kWavesPerBlock];
-    if (st->done || st->iters == 0) return;          // iteration 0: no step has been taken yet (a warm start is judged by k_warm_scale)
-    const T rdr = block_sum_array<T>(rdr_part, n, red);
-    const T bdb = block_sum_array<T>(bpart, n, red);
+    const int done = st->done, iters = st->iters;
+    T a = 0, b = 0;                                  // the partials are on their way while the state is looked at
+    for (int k = threadIdx.x; k < n; k += kBlock) { a += rdr_part[k]; b += bpart[k]; }
+    issue_before_exit(a);
+    if (done || iters == 0) return;                  // iteration 0: no step has been taken yet (a warm start is judged by k_warm_scale)
+    const T rdr = block_sum<T>(a, red);
+    const T bdb = block_sum<T>(b, red);
     if (threadIdx.x == 0 && !(rdr > tol2 * bdb)) { st->done = 1; st->fail = (rdr != rdr) ? 1 : 0; }      // NaN: breakdown
 }
 

@@ -205,6 +205,7 @@ template <typename T> struct Engine : IEngine {
     T *ps = nullptr, *theta = nullptr, *lmrec = nullptr, *gauge_p = nullptr, *gauge_l = nullptr;
     Table<T> tp{}, tl{}, to{};
     T *part = nullptr, *dp = nullptr, *minv = nullptr, *r = nullptr, *p = nullptr, *q = nullptr, *x = nullptr, *zc = nullptr;
+    float *zc32 = nullptr, *tvec32 = nullptr;      // f32 copies of the gathered records, read by the two products inside the multigrid cycle
     T *sbuf = nullptr, *tvec = nullptr, *ninv = nullptr, *dl = nullptr, *gpart[2] = {nullptr, nullptr}, *npart = nullptr;
     CgState<T>* st[2] = {nullptr, nullptr};
     CgState<T>* h_state = nullptr;     // pinned
@@ -566,6 +567,7 @@ template <typename T> struct Engine : IEngine {
         BuildOptions bo; bo.rank = cfg.rank; bo.world = cfg.world; bo.lanes_per_pose = cfg.lanes_per_pose; bo.lanes_per_lm = cfg.lanes_per_lm;
         bo.fill_planes = false;
         const std::string err = build_problem(g, bo, pr);
+        od_live = -1;
         if (!err.empty()) return set_error(-2, "tsgo_set_graph: " + err);
         pr.odom_analytic = oj();
         const bool say = cfg.verbose || getenv("TSGO_VERBOSE");
@@ -602,6 +604,9 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&x, (size_t)P * 3)) return rc;
         if (int rc = dalloc(&zc, (size_t)P * kPoseRec)) return rc;
         { if (int rc_ = fill_zero(zc, (size_t)P * kPoseRec * sizeof(T))) return rc_; }
+        if (int rc = dalloc(&zc32, (size_t)P * kPoseRec)) return rc;
+        { if (int rc_ = fill_zero(zc32, (size_t)P * kPoseRec * sizeof(float))) return rc_; }
+        if (int rc = dalloc(&tvec32, (size_t)std::max(L, 1) * 2)) return rc;
         if (int rc = dalloc(&sbuf, (size_t)P * 3 + nbP)) return rc;
         if (int rc = dalloc(&tvec, (size_t)std::max(L, 1) * 2)) return rc;
         if (int rc = dalloc(&ninv, (size_t)std::max(L, 1) * kNinvRec)) return rc;
@@ -652,9 +657,10 @@ template <typename T> struct Engine : IEngine {
     }
     std::string lvl(const char* role, size_t l) const { return std::string(role) + " L" + std::to_string(l); }
     // algorithmic bytes of the table kernels and of the block-row kernels of the cycle
-    double od_slots_live() const { double od = 0; for (uint32_t e : pr.odom.edge) od += e != kNoEdge; return od; }     // profile / probes only
+    double od_live = -1;      // live ODOM slots of this shard (the byte models'), counted once per structure
+    double od_slots_live() { if (od_live < 0) { od_live = 0; for (uint32_t e : pr.odom.edge) od_live += e != kNoEdge; } return od_live; }
     double bytes_schur_lm(bool low) const { const double s = low ? 4 : sizeof(T), v = sizeof(T); return (double)pr.n_lm_edges * (4 + 4 * s) + pr.P * 5.0 * v + pr.L * 5.0 * v; }
-    double bytes_schur_pose(bool low) const { const double s = low ? 4 : sizeof(T), v = sizeof(T); return (double)pr.n_lm_edges * (4 + 4 * s) + pr.L * 2.0 * v + pr.P * 14.0 * v + od_slots_live() * (4 + 6 * v); }
+    double bytes_schur_pose(bool low) { const double s = low ? 4 : sizeof(T), v = sizeof(T); return (double)pr.n_lm_edges * (4 + 4 * s) + pr.L * 2.0 * v + pr.P * 14.0 * v + od_slots_live() * (4 + 6 * v); }
     double bytes_sweep(const DevLevel<T>& L) const { return (double)L.nnzA * (4.0 * cyw() + 4) + (double)L.n * (3 * 3 * sizeof(T) + 9 * sizeof(H) + 4); }
     double bytes_transfer(const DevLevel<T>& L, int vecs_fine) const { return (double)L.nnzP * (4.0 * cyw() + 4) + (double)L.n * 3 * sizeof(T) * vecs_fine + (double)L.n_agg * (3 * sizeof(T) + 4); }
 
@@ -676,7 +682,7 @@ template <typename T> struct Engine : IEngine {
         else LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
     }
     void launch_finalize() {
-        hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0], (const T*)(amg_on ? omega_dev : one_dev), gscale_dev);
+        hipLaunchKernelGGL((k_pose_finalize<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, part, ps, dp, minv, r, p, q, x, zc, gpart[0], st[0], (const T*)(amg_on ? omega_dev : one_dev), gscale_dev, amg_on && low_cycle ? zc32 : (float*)nullptr);
     }
     // S * (vector in zc) -> sbuf, dot partials behind it.  low: read the f32 copy of the slot planes (the two
     // products inside the multigrid cycle; never the product PCG itself takes).
@@ -687,12 +693,12 @@ template <typename T> struct Engine : IEngine {
         const char* wh = low ? "in-cycle product" : (with_rz ? "PCG product" : "product");
         if (low) {
             PF(bytes_schur_lm(true), wh, "k_schur_lm<%s, %d, 0, 1>", tname(), pr.by_lm.G);
-            if (tl.n_slices > 0) LAUNCH_GML(pr.by_lm.G, k_schur_lm, 0, 1, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
+            if (tl.n_slices > 0) LAUNCH_GML(pr.by_lm.G, k_schur_lm, 0, 1, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart, (const float*)zc32, tvec32);
             PF(bytes_schur_pose(true), wh, "k_schur_pose<%s, %d, 1, %d>", tname(), pr.by_pose.G, oj() ? 1 : 0);
             if (oj()) LAUNCH_GML(pr.by_pose.G, k_schur_pose, 1, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
-                                 (const T*)nullptr, rzpart);
+                                 (const T*)nullptr, rzpart, (const float*)zc32, (const float*)tvec32);
             else LAUNCH_GML1(pr.by_pose.G, k_schur_pose, 1, nbP, stream, tp, to, zc, tvec, dp, pr.pose_first, pr.pose_last, sbuf, sbuf + (size_t)pr.P * 3, st[slot],
-                             (const T*)nullptr, rzpart);
+                             (const T*)nullptr, rzpart, (const float*)zc32, (const float*)tvec32);
         } else {
             PF(bytes_schur_lm(false), wh, "k_schur_lm<%s, %d, 0, 0>", tname(), pr.by_lm.G);
             if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 0, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[slot], T(0), dl, npart);
@@ -784,8 +790,9 @@ template <typename T> struct Engine : IEngine {
     void launch_prolong(DevLevel<T>& L, const T* e, T* z, int zs, const CgState<T>* s, size_t level) {
         PF(bytes_transfer(L, 2), lvl("prolong into", level).c_str(), "k_prolong_add<%s, %d, %d>", tname(), lanes_for((double)L.nnzP / std::max(1, L.n)), cy16 ? 1 : 0);
         const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n));
-        if (cy16) LAUNCH_LPR_(lpr, PROLONG_INST16, L.n, L.n, L.P_ptr, L.P_col, (const uint32_t*)L.Ppm, e, z, zs, s);
-        else LAUNCH_LPR_(lpr, PROLONG_INST32, L.n, L.n, L.P_ptr, L.P_col, (const uint32_t*)L.Ppm, e, z, zs, s);
+        float* z32 = (level == 0 && low_cycle && !explicit0) ? zc32 : (float*)nullptr;      // level 0 prolongs into the pose records: keep their f32 copy current
+        if (cy16) LAUNCH_LPR_(lpr, PROLONG_INST16, L.n, L.n, L.P_ptr, L.P_col, (const uint32_t*)L.Ppm, e, z, zs, s, z32);
+        else LAUNCH_LPR_(lpr, PROLONG_INST32, L.n, L.n, L.P_ptr, L.P_col, (const uint32_t*)L.Ppm, e, z, zs, s, z32);
     }
 
     // Damping of the block-Jacobi smoother per level from a power iteration on D^-1 A (12 steps): the V-cycle
@@ -923,7 +930,7 @@ template <typename T> struct Engine : IEngine {
         PF(pr.P * (3 + 3 + 6 + 4 * 3 * 2) * (double)sizeof(T), "vector step + pre-smoothing L0", "k_cg_step<%s>", tname());
         hipLaunchKernelGGL((k_cg_step<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)(sbuf + (size_t)pr.P * 3), (const T*)rzpart, nbP,
                            (const CgState<T>*)st[slot], st[slot ^ 1], r, p, q, x, zc, (const T*)minv, (const T*)omega_dev, tol2, cfg.pcg_max_iters, (const T*)gscale_dev, kAmgStallIter, (T)kAmgStallRatio,
-                           npart);
+                           npart, low_cycle && !explicit0 ? zc32 : (float*)nullptr);
     }
     // one PCG iteration reading state slot `slot`, writing slot^1
     int launch_iteration(int slot) {
@@ -1038,7 +1045,7 @@ template <typename T> struct Engine : IEngine {
         else
             hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, a, (const T*)nullptr, T(0));
         if (int rc = launch_matvec(0)) return rc;
-        hipLaunchKernelGGL((k_warm_residual<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)minv, r, zc, (const T*)(amg_on ? omega_dev : one_dev), npart);
+        hipLaunchKernelGGL((k_warm_residual<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)minv, r, zc, (const T*)(amg_on ? omega_dev : one_dev), npart, amg_on && low_cycle ? zc32 : (float*)nullptr);
         hipLaunchKernelGGL((k_warm_scale<T>), dim3(1), dim3(kBlock), 0, stream, nbC, (const T*)gpart[0], (const T*)npart, amg_on ? (T*)nullptr : gpart[0], gscale_dev,
                            amg_on ? st[0] : (CgState<T>*)nullptr, (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol));
         return 0;

@@ -48,6 +48,10 @@ template <typename T> __device__ __forceinline__ void st2(T* p, T a, T b) {
     *reinterpret_cast<typename Pair<T>::type*>(p) = v;
 }
 
+// Keeps the compiler from sinking a load below an early exit: the value must exist when this statement is reached, so the load
+// that produces it is issued (and waited for) before the test that follows — beside the flag's own load instead of behind it.
+template <typename V> __device__ __forceinline__ void issue_before_exit(V& v) { asm volatile("" : "+v"(v)); }
+
 template <typename T> struct CgState { T gamma_old, alpha_old, gamma0, pad; int iters, done, fail, pad2; };
 
 // LM tables keep their per-slot values as 16-byte PAIRS, pair-plane-major: st = [(zx,zy) | (w0,w1)],
@@ -274,7 +278,7 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __rest
                                                           T* __restrict__ p, T* __restrict__ q, T* __restrict__ x,
                                                           T* __restrict__ zc, T* __restrict__ gpart,
                                                           CgState<T>* __restrict__ st0, const T* __restrict__ omega_ptr,
-                                                          T* __restrict__ gamma0_scale) {
+                                                          T* __restrict__ gamma0_scale, float* __restrict__ zc32) {
     __shared__ T red[kWavesPerBlock];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     T g = 0;
@@ -295,6 +299,11 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __rest
         T* zr = zc + (size_t)i * kPoseRec;
         const T w = *omega_ptr;    // 1 for block-Jacobi PCG; the level-0 smoother damping under the multigrid cycle
         zr[0] = w * z0; zr[1] = w * z1; zr[2] = w * z2; zr[3] = ps[(size_t)i * 4 + 2]; zr[4] = ps[(size_t)i * 4 + 3];
+        if (zc32) {     // f32 copy of the record for the products inside the multigrid cycle (k_schur_lm / k_schur_pose, LOW)
+            float* zq = zc32 + (size_t)i * kPoseRec;
+            *reinterpret_cast<float4*>(zq) = make_float4((float)(w * z0), (float)(w * z1), (float)(w * z2), (float)zr[3]);
+            zq[4] = (float)zr[4];
+        }
         g = r0 * z0 + r1 * z1 + r2 * z2;
     }
     const T total = block_sum<T>(g, red);
@@ -313,9 +322,12 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(int P, const T* __rest
 template <typename T, int G, int MODE, int LOW = 0>
 __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __restrict__ zc, T* __restrict__ lmrec,
                                                      const T* __restrict__ ninv, T* __restrict__ t, const CgState<T>* __restrict__ st,
-                                                     T step, T* __restrict__ dl_out, T* __restrict__ norm_part) {
+                                                     T step, T* __restrict__ dl_out, T* __restrict__ norm_part,
+                                                     const float* __restrict__ zc32 = nullptr, float* __restrict__ t32 = nullptr) {
     __shared__ T red[kWavesPerBlock];
-    if (MODE == 0 && st->done) return;
+    // the flag of a finished solve is requested here and tested after the loads that depend on the arguments alone (row bounds,
+    // the vertex's inverse block) are on their way: tested first, it adds a scalar round trip in front of the first vector load
+    const int done = MODE == 0 ? st->done : 0;
     const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
     const int lane = threadIdx.x & 63;
@@ -329,7 +341,9 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
         // the inverse block this vertex needs at the very end is requested first: its latency hides behind the rows
         const int lq = (l < tb.n_vertices) ? l : tb.n_vertices - 1;
         const auto n01 = ld2<T>(ninv + (size_t)lq * kNinvRec);
-        const T n2 = ninv[(size_t)lq * kNinvRec + 2];
+        T n2 = ninv[(size_t)lq * kNinvRec + 2];
+        issue_before_exit(n2);
+        if (done) return;
         // UB rows are walked at a time with every load of the batch issued before any use: a wave's time is
         // the depth of its dependent-load chain (row -> index -> gathered pose record), so memory-level
         // parallelism is what buys time.  Rows past the end are clamped (in bounds) and masked out of the sums.
@@ -350,9 +364,15 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
             T v0[UB], v1[UB], v2[UB], c[UB], s[UB];
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
-                const T* zr = zc + (size_t)i[u] * kPoseRec;
-                const auto z01 = ld2<T>(zr), z23 = ld2<T>(zr + 2);
-                v0[u] = z01.x; v1[u] = z01.y; v2[u] = z23.x; c[u] = z23.y; s[u] = zr[4];
+                if (LOW) {      // the f32 copy of the pose records (32 B each): half the bytes gathered through L2
+                    const float* zr = zc32 + (size_t)i[u] * kPoseRec;
+                    const float4 q = *reinterpret_cast<const float4*>(zr);
+                    v0[u] = q.x; v1[u] = q.y; v2[u] = q.z; c[u] = q.w; s[u] = zr[4];
+                } else {
+                    const T* zr = zc + (size_t)i[u] * kPoseRec;
+                    const auto z01 = ld2<T>(zr), z23 = ld2<T>(zr + 2);
+                    v0[u] = z01.x; v1[u] = z01.y; v2[u] = z23.x; c[u] = z23.y; s[u] = zr[4];
+                }
             }
 #pragma unroll
             for (int u = 0; u < UB; ++u) {
@@ -368,7 +388,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
             T* lr = lmrec + (size_t)l * kLmRec;
             const T ixx = n01.x, ixy = n01.y, iyy = n2;
             const T t0 = ixx * acc0 + ixy * acc1, t1 = ixy * acc0 + iyy * acc1;
-            if (MODE == 0) { t[(size_t)l * 2] = t0; t[(size_t)l * 2 + 1] = t1; }
+            if (MODE == 0) {
+                if (LOW) *reinterpret_cast<float2*>(t32 + (size_t)l * 2) = make_float2((float)t0, (float)t1);
+                else { t[(size_t)l * 2] = t0; t[(size_t)l * 2 + 1] = t1; }
+            }
             else {
                 const T d0 = lr[5] - t0, d1 = lr[6] - t1;
                 dl_out[(size_t)l * 2] = d0; dl_out[(size_t)l * 2 + 1] = d1;
@@ -377,6 +400,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __res
             }
         }
     }
+    else if (done) return;
     if (MODE == 1) {
         const T total = block_sum<T>(nrm, red);
         if (threadIdx.x == 0) norm_part[blockIdx.x] = total;
@@ -391,20 +415,26 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
                                                        const T* __restrict__ t, const T* __restrict__ dp,
                                                        int pose_first, int pose_last, T* __restrict__ out,
                                                        T* __restrict__ dot_part, const CgState<T>* __restrict__ st,
-                                                       const T* __restrict__ rvec, T* __restrict__ rz_part) {
+                                                       const T* __restrict__ rvec, T* __restrict__ rz_part,
+                                                       const float* __restrict__ zc32 = nullptr, const float* __restrict__ t32 = nullptr) {
     __shared__ T red[kWavesPerBlock];
-    if (st->done) return;
+    const int done = st->done;      // requested now, tested after the first argument-only loads are in flight (see k_schur_lm)
     const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
     const int lane = threadIdx.x & 63;
     constexpr int VPS = 64 / G;
     const int i = slice * VPS + lane / G;
     T dot = 0, rz = 0;
+    if (!live && done) return;      // workgroup-uniform: done is, and the other waves of the group leave below
     if (live) {
         const bool valid = i < tb.n_vertices;
         const int ic = valid ? i : tb.n_vertices - 1;
-        const T* zr = zc + (size_t)ic * kPoseRec;
-        const T v0 = zr[0], v1 = zr[1], v2 = zr[2], c = zr[3], s = zr[4];
+        T v0, v1, v2, c, s;
+        if (LOW) { const float* zr = zc32 + (size_t)ic * kPoseRec; v0 = zr[0]; v1 = zr[1]; v2 = zr[2]; c = zr[3]; s = zr[4]; }
+        else { const T* zr = zc + (size_t)ic * kPoseRec; v0 = zr[0]; v1 = zr[1]; v2 = zr[2]; c = zr[3]; s = zr[4]; }
+        const uint32_t lm_r0 = tb.row_off[slice], lm_r1 = tb.row_off[slice + 1];
+        issue_before_exit(v0);
+        if (done) return;
         // the pose's own diagonal block and residual entry are used at the very end: asked for first
         const bool head = valid && (lane % G) == 0;
         const bool own = head && i >= pose_first && i < pose_last;
@@ -417,7 +447,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
         T acc0 = 0, acc1 = 0, acc2 = 0;
         {
             const size_t S = tb.slots;
-            const uint32_t r0 = tb.row_off[slice], r1 = tb.row_off[slice + 1];
+            const uint32_t r0 = lm_r0, r1 = lm_r1;
 #pragma unroll 2
             for (uint32_t row = r0; row < r1; ++row) {
                 const size_t k = (size_t)row * 64 + lane;
@@ -428,8 +458,9 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
                     const auto aa = ld2<T>(tb.dyn + 2 * k), pp = ld2<T>(tb.dyn + 2 * (S + k));
                     a0 = aa.x; a1 = aa.y; ppx = pp.x; ppy = pp.y;
                 }
-                const auto txy = ld2<T>(t + (size_t)l * 2);
-                const T tx = txy.x, ty = txy.y;
+                T tx, ty;
+                if (LOW) { const float2 txy = *reinterpret_cast<const float2*>(t32 + (size_t)l * 2); tx = txy.x; ty = txy.y; }
+                else { const auto txy = ld2<T>(t + (size_t)l * 2); tx = txy.x; ty = txy.y; }
                 const T t0 = a0 * (c * tx + s * ty), t1 = a1 * (c * ty - s * tx);
                 acc0 += t0; acc1 += t1; acc2 += t0 * ppy - t1 * ppx;
             }
@@ -442,7 +473,9 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
                 const size_t k = (size_t)row * 64 + lane;
                 const uint32_t raw = od.idx[k];
                 const uint32_t j = raw & ~kDirMask;
-                const T* zj = zc + (size_t)j * kPoseRec;
+                T zj[3];
+                if (LOW) { const float* q = zc32 + (size_t)j * kPoseRec; zj[0] = q[0]; zj[1] = q[1]; zj[2] = q[2]; }
+                else { const T* q = zc + (size_t)j * kPoseRec; zj[0] = q[0]; zj[1] = q[1]; zj[2] = q[2]; }
                 if (OJ) {           // H_12 = [[-K, 0], [g^T, -w]] seen from the first endpoint, its transpose from the second
                     const T k00 = od.dyn[k], k01 = od.dyn[S + k], k11 = od.dyn[2 * S + k], g0 = od.dyn[3 * S + k], g1 = od.dyn[4 * S + k], w = od.dyn[5 * S + k];
                     const T zt0 = zj[0], zt1 = zj[1], zth = zj[2];
@@ -559,7 +592,7 @@ __global__ __launch_bounds__(kBlock) void k_pack_x(int P, T* __restrict__ x, T* 
 // Warm start, second half: r = b~ - S x0 (S x0 in sx), zc = omega Minv r, partials of r^T Minv r.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_warm_residual(int P, const T* __restrict__ sx, const T* __restrict__ minv, T* __restrict__ r,
-                                                          T* __restrict__ zc, const T* __restrict__ omega_ptr, T* __restrict__ part) {
+                                                          T* __restrict__ zc, const T* __restrict__ omega_ptr, T* __restrict__ part, float* __restrict__ zc32) {
     __shared__ T red[kWavesPerBlock];
     const int i = blockIdx.x * kBlock + threadIdx.x;
     T g = 0;
@@ -571,6 +604,7 @@ __global__ __launch_bounds__(kBlock) void k_warm_residual(int P, const T* __rest
         const T w = *omega_ptr;
         T* zr = zc + (size_t)i * kPoseRec;
         zr[0] = w * z0; zr[1] = w * z1; zr[2] = w * z2;
+        if (zc32) { float* zq = zc32 + (size_t)i * kPoseRec; zq[0] = (float)(w * z0); zq[1] = (float)(w * z1); zq[2] = (float)(w * z2); }
         g = r0 * z0 + r1 * z1 + r2 * z2;
     }
     const T total = block_sum<T>(g, red);

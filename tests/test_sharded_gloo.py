@@ -16,6 +16,13 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+@pytest.fixture(autouse=True)
+def _passive_openmp(monkeypatch):
+    """Ranks waiting in a gloo all-reduce must not spin (libgomp's default wait policy) on the CPUs the other ranks need: the spawned
+    workers inherit this."""
+    monkeypatch.setenv("OMP_WAIT_POLICY", "PASSIVE")
+
+
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
     return p
@@ -23,7 +30,7 @@ def _free_port():
 
 def _worker(rank, world, port, out_dir, n_poses, precond, rules, explicit_cycle=False):
     sys.path.insert(0, ROOT)
-    torch.set_num_threads(2)      # also sizes the twin's OpenMP loops (same libgomp)
+    torch.set_num_threads(2 if world <= 3 else 1)      # also sizes the twin's OpenMP loops (same libgomp); eight ranks share this box's eight CPUs
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
@@ -50,7 +57,7 @@ def _worker(rank, world, port, out_dir, n_poses, precond, rules, explicit_cycle=
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,precond,n_poses,rules", [(2, "jacobi", 300, "cpp"), (2, "amg", 1500, "cpp"), (3, "amg", 700, "cpp"), (2, "amg", 600, "python")])
+@pytest.mark.parametrize("world,precond,n_poses,rules", [(2, "jacobi", 300, "cpp"), (2, "amg", 1500, "cpp"), (3, "amg", 700, "cpp"), (2, "amg", 600, "python"), (8, "amg", 2400, "cpp")])
 def test_sharded_run_across_processes_matches_single_process(tmp_path, world, precond, n_poses, rules):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_poses, precond, rules), nprocs=world, join=True)
     from oracle import oracle

@@ -233,10 +233,8 @@ template <typename T> struct Engine : IEngine {
     int n_prev = 0;                    // how many consecutive deltas are held (xprev, xprev2)
     int coarse_sweeps = kCoarseSweeps;
     std::vector<int> sweeps_list;      // research: sweeps per side on levels 1, 2, ... (TSGO_SWEEPS_LIST="2,2,1"; the last entry repeats)
-    bool sweeps_forced = false;        // TSGO_COARSE_SWEEPS given: the same count on every coarse level
     int nu_at(size_t l) const {
         if (!sweeps_list.empty()) return sweeps_list[std::min(l - 1, sweeps_list.size() - 1)];
-        if (sweeps_forced) return coarse_sweeps;
         return lv[l].n <= kSmallLevelRows ? kSmallLevelSweeps : coarse_sweeps;
     }
     bool low_cycle = true;     // f32 slot planes for the Schur products inside the multigrid cycle
@@ -244,9 +242,7 @@ template <typename T> struct Engine : IEngine {
     size_t cyw() const { return cy16 ? (size_t)kCyWordsF16 : (size_t)kCyWordsF32; }
 
     explicit Engine(const tsgo_config& c) : cfg(c) {
-        if (const char* e = getenv("TSGO_COARSE_SWEEPS")) { coarse_sweeps = std::max(1, std::min(4, atoi(e))); sweeps_forced = true; }
         if (const char* e = getenv("TSGO_SWEEPS_LIST")) for (const char* q = e; *q;) { sweeps_list.push_back(std::max(1, std::min(4, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
-        if (const char* e = getenv("TSGO_CYCLE_F64")) low_cycle = atoi(e) == 0;
         explicit0 = c.cycle_level0 != 0;
         cy16 = c.cycle_storage != 32;
         if (const char* e = getenv("TSGO_HIER_MAX_AGE")) hier_max_age = std::max(1, atoi(e));
@@ -748,9 +744,7 @@ template <typename T> struct Engine : IEngine {
     }
 
     static int lanes_for(double avg_row) {
-        static const int shift = getenv("TSGO_LPR_SHIFT") ? atoi(getenv("TSGO_LPR_SHIFT")) : 0;      // research: fewer lanes per row
-        const int l = avg_row <= 4 ? 4 : (avg_row <= 12 ? 8 : (avg_row <= 40 ? 32 : 64));
-        return std::max(4, l >> shift);
+        return avg_row <= 4 ? 4 : (avg_row <= 12 ? 8 : (avg_row <= 40 ? 32 : 64));
     }
     // Block-row sweeps (k_bcsr_residual): on the big levels (thousands of rows: every wave slot of the device is taken more
     // than once) a lane should carry two to four blocks, not one — 16 lanes per row at 28 and at 67 blocks per row measured
@@ -947,8 +941,7 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
     int chunk() const {
-        static const int env = getenv("TSGO_CHUNK_AMG") ? std::max(2, atoi(getenv("TSGO_CHUNK_AMG")) & ~1) : 0;     // research: iterations per captured graph (even)
-        return amg_on ? (env ? env : kChunkAmg) : kChunk;
+        return amg_on ? kChunkAmg : kChunk;
     }
     void launch_cg_update(int slot) {
         const T tol2 = (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol);

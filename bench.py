@@ -25,6 +25,7 @@ of the same math on the host cores, and the reference's dense algorithm at confi
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -226,7 +227,9 @@ def main():
         tname = "double" if ARGS.precision == 64 else "float"
         for which in (0, 1, 2, 3, 4):
             us, nbytes = opt.time_kernel(which, reps=200)
-            hit = [n for n in shares if n.startswith(KERNELS[which] + "<" + tname) and (which >= 2 or ", 0, 0>" in n or n.endswith(", 0>"))]
+            # the instantiation tsgo_time_kernel launches: f64 / f32 slot planes in T, product mode (k_schur_lm<T, G, 0, 0>, k_schur_pose<T, G, 0, OJ>)
+            pat = {0: r"k_schur_lm<%s, \d+, 0, 0>$", 1: r"k_schur_pose<%s, \d+, 0, \d>$"}.get(which, KERNELS[which] + r"<%s[,>]")
+            hit = [n for n in shares if re.match(pat % tname, n)]
             if hit:
                 shares[hit[0]]["us_back_to_back"] = us
             elif which >= 3:      # the two linearisation kernels run once per step, outside the PCG iteration

@@ -89,7 +89,8 @@ typedef struct tsgo_config {
     int32_t cycle_storage;   /* 16 (default) or 32: how the copies of the hierarchy's matrices that the V-cycle reads (A_l, P_l, R_l, l >= 0) are
                                 stored — nine half floats with a common power-of-two exponent per 3x3 block (20 bytes), or nine f32 (36
                                 bytes).  A preconditioner tolerates the 11-bit blocks; PCG's own operator and every vector stay in
-                                `precision`.  Same answers, the same or one more PCG iteration per solve, fewer bytes per iteration. */
+                                `precision`.  Same answers, the same or one more PCG iteration per solve, fewer bytes per iteration.  A structure whose solves
+                                take more than 64 iterations (nearly singular systems: long odometry-only chains) is moved to 32 by the engine. */
 } tsgo_config;
 
 enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_CONVERGED = 3, TSGO_STOP_SOLVER = 4 };
@@ -104,7 +105,9 @@ typedef struct tsgo_stats {
     double ms_total, ms_linearize, ms_solve, ms_update;   /* device time, hipEvent */
     double ms_setup;                     /* tsgo_set_graph: host layout build + upload, or the refill when the structure was reused */
     int32_t structure_reused;            /* 1 when the last tsgo_set_graph found the same structure and only refilled values */
-    int32_t reserved;
+    int32_t cycle_storage_now;           /* what the multigrid cycle of this structure reads now: 16 (packed halves) or 32 (f32: chosen by
+                                            tsgo_config.cycle_storage, or by the engine after a solve of more than 64 iterations — a graph too
+                                            ill-conditioned for 11-bit blocks); 0 with block-Jacobi */
     double lambda_last;                  /* rules = 1: the damping used by the last iteration */
     int64_t n_pose, n_lm, n_odom_edges, n_lm_edges;
     int64_t pcg_iters_total;
@@ -187,7 +190,9 @@ typedef struct tsgo_prof_entry {
     char name[64];
     char where[32];
     int32_t launches_per_iteration;
-    int32_t reserved;
+    int32_t cycle_storage_now;           /* what the multigrid cycle of this structure reads now: 16 (packed halves) or 32 (f32: chosen by
+                                            tsgo_config.cycle_storage, or by the engine after a solve of more than 64 iterations — a graph too
+                                            ill-conditioned for 11-bit blocks); 0 with block-Jacobi */
     double us, bytes;
 } tsgo_prof_entry;
 int tsgo_profile_iteration(tsgo_optimizer* opt, int32_t reps, tsgo_prof_entry* out, int32_t cap);

@@ -31,7 +31,9 @@ while time.time() < t_end:
     fx = [0] + [int(v) for v in rng.choice(g.v_id, size=int(rng.integers(0, 3)), replace=False)]
     g.fixed = np.array(fx, np.uint32)
     oj = "analytic" if trial % 4 == 1 else "constant"
-    if oj == "analytic" and shape == "pose graph" and n > 25000:      # beam-like chain: thousands of PCG iterations per solve; the CPU twin needs minutes
+    if oj == "analytic" and shape == "pose graph" and n > 15000:      # beam-like chain: thousands of PCG iterations per solve; the CPU twin needs minutes,
+        # and under round 3's stopping rule (the residual in the D^-1 norm, not r^T M^-1 r) a 24k-link beam needs 5 000 - 15 000+ multigrid
+        # iterations per solve — past the default pcg_max_iters of 20 000 (profiles/r03k_hard_chain.txt, r03m_soak_*)
         # (and at 36 k poses two solves to 1e-11 / 1e-12 — 2 000 ... 12 000 iterations each — end 3.9e-4 apart: profiles/r02t_soak_kept_handles.log)
         oj = "constant"
     rules, lr = ("python", float(rng.choice([0.2, 0.5, 1.0]))) if trial % 5 == 2 else ("cpp", 0.2)

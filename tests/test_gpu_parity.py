@@ -443,6 +443,29 @@ def test_ill_conditioned_chain_leaves_the_packed_cycle_format_by_itself():
     assert util.max_vertex_diff(v16, v32, g.v_type) < 1e-3 * max(1.0, float(np.abs(v32).max()) / 100.0)      # the conditioning of a 12k-link beam
 
 
+@pytest.mark.parametrize("n_poses,lc", [(3000, 20), (30000, 300)])
+def test_pair_lists_built_on_the_device_equal_the_hosts(monkeypatch, n_poses, lc):
+    """The hierarchy's pair-list products (T = A P, A' = P^T T on every level) are built on the device (tsgo_sym_kernels.h) with the
+    same columns in the same order and the same pairs in the same order as the host builder's (TSGO_HOST_PRODUCTS=1): every number
+    computed from them is then the same bit for bit — chi^2, PCG iteration counts, vertices."""
+    g = synth.make(n_poses, 10, loop_closures=lc, seed=41)
+    res = {}
+    for host in (True, False):
+        if host:
+            monkeypatch.setenv("TSGO_HOST_PRODUCTS", "1")
+        else:
+            monkeypatch.delenv("TSGO_HOST_PRODUCTS", raising=False)
+        o = HipOptimizer(pcg_rel_tol=1e-12)
+        try:
+            o.set_graph(g); res[host] = (o.optimize(5), o.vertices())
+        finally:
+            o.close()
+    (rh, vh), (rd, vd) = res[True], res[False]
+    np.testing.assert_array_equal(rd["chi2"], rh["chi2"])
+    np.testing.assert_array_equal(rd["cg_iters"], rh["cg_iters"])
+    np.testing.assert_array_equal(vd, vh)
+
+
 def test_rejects_bad_graphs_without_crashing(opt):
     g = util.tiny_arrays("tiny_a")
     bad = g.copy(); bad.e_ids[1, 1] = 999

@@ -27,6 +27,7 @@
 #include "host/problem.h"
 #include "tsgo_amg_kernels.h"
 #include "tsgo_kernels.h"
+#include "tsgo_sym_kernels.h"
 
 namespace {
 
@@ -160,6 +161,8 @@ template <typename T> struct DevLevel {      // device copy of one AmgLevel (hos
     int *R_ptr = nullptr, *R_col = nullptr, *r_to_p = nullptr, *p_to_r = nullptr;
     int *ts_ptr = nullptr, *ts_x = nullptr, *ts_y = nullptr, *as_ptr = nullptr, *as_x = nullptr, *as_y = nullptr, *as_mirror = nullptr, *as_upper = nullptr;
     int n_upper = 0;
+    bool patterns_up = false;      // A / P / R patterns are on the device already (the device built this level's pair-list products)
+    bool products_dev = false;     // ts_* / as_* were built on the device (tsgo_sym_kernels.h): nothing of them exists on the host
     using H = HT<T>;                              // hierarchy storage type (tsgo_amg_kernels.h)
     T* rel = nullptr;
     H *A = nullptr, *Dinv = nullptr, *P = nullptr, *Tv = nullptr, *Rv = nullptr;
@@ -248,6 +251,7 @@ template <typename T> struct Engine : IEngine {
         if (const char* e = getenv("TSGO_SWEEPS_LIST")) for (const char* q = e; *q;) { sweeps_list.push_back(std::max(1, std::min(4, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
         explicit0 = c.cycle_level0 != 0;
         cy16 = c.cycle_storage != 32;
+        if (const char* e = getenv("TSGO_HOST_PRODUCTS")) device_products = atoi(e) == 0;
         if (const char* e = getenv("TSGO_HIER_MAX_AGE")) hier_max_age = std::max(1, atoi(e));
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
@@ -336,13 +340,29 @@ template <typename T> struct Engine : IEngine {
     std::string amg_builder_error;
     std::mutex amg_mu; std::condition_variable amg_cv;
     bool amg_schur_ready = false, amg_finished = false; int amg_levels_ready = 0;
+    // The builder thread asks the calling thread (the only one that touches the device and the slab allocator) to build a level's
+    // two pair-list products on the device, and waits for the next matrix's pattern (AmgProgress::products).
+    struct ProductRequest { int level = -1; AmgLevel* L = nullptr; BlockCsr* A_next = nullptr; bool pending = false, done = false, accepted = false; std::string err; } preq;
+    bool products_open = false;      // false: nobody is (any longer) serving requests — the builder does the products itself
+    bool device_products = true;     // research switch TSGO_HOST_PRODUCTS=1: every pair list on the host, as rounds 1-2
     void start_amg_builder(const tsgo_graph& g) {
         amg_schur_ready = amg_finished = false; amg_levels_ready = 0;
+        preq = ProductRequest(); products_open = device_products && pr.world == 1;
         amg_builder = std::thread([this, &g] {      // g is borrowed for the whole tsgo_set_graph call, which joins this thread
             const auto t0 = std::chrono::steady_clock::now();
             AmgProgress pg;
             pg.schur_ready = [this] { { std::lock_guard<std::mutex> l(amg_mu); amg_schur_ready = true; } amg_cv.notify_all(); };
             pg.level_ready = [this](int n) { { std::lock_guard<std::mutex> l(amg_mu); amg_levels_ready = n; } amg_cv.notify_all(); };
+            pg.products = [this](int level, AmgLevel& L, BlockCsr& A_next, std::string& err) -> bool {
+                std::unique_lock<std::mutex> l(amg_mu);
+                if (!products_open) return false;
+                preq.level = level; preq.L = &L; preq.A_next = &A_next; preq.pending = true; preq.done = false; preq.accepted = false; preq.err.clear();
+                amg_cv.notify_all();
+                amg_cv.wait(l, [&] { return preq.done || !products_open; });
+                if (!preq.done) { preq.pending = false; return false; }        // the server of requests has left (an error on its side): do it here
+                err = preq.err;
+                return preq.accepted;
+            };
             amg_builder_error = pr.world > 1 ? build_amg_sharded(g, pr, amg) : build_amg(pr, amg, &pg);
             ms_amg_symbolic = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             { std::lock_guard<std::mutex> l(amg_mu); amg_finished = true; }
@@ -364,16 +384,19 @@ template <typename T> struct Engine : IEngine {
     }
     int upload_level(size_t l) {
         const AmgLevel& L = amg.levels[l]; DevLevel<T>& D = lv[l];
-        D.n = L.n; D.n_agg = L.n_agg; D.nnzA = L.A.nnz(); D.nnzP = L.P.nnz(); D.nnzT = L.T.nnz(); D.nnzNext = (int)L.a_src.ptr.size() - 1;
-        D.pairs_T = (double)L.t_src.x.size() / std::max(1, D.nnzT); D.pairs_A = (double)L.a_src.x.size() / std::max<double>(1, (double)std::count(L.a_mirror.begin(), L.a_mirror.end(), -1));
-        UP(D.A_ptr, L.A.ptr); UP(D.A_col, L.A.col); UP(D.A_row, rows_of(L.A)); UP(D.diag, L.diag);
-        UP(D.P_ptr, L.P.ptr); UP(D.P_col, L.P.col); UP(D.P_row, rows_of(L.P)); UP(D.p_self, L.p_self);
+        D.n = L.n; D.n_agg = L.n_agg; D.nnzA = L.A.nnz(); D.nnzP = L.P.nnz();
+        if (!D.patterns_up) { UP(D.A_ptr, L.A.ptr); UP(D.A_col, L.A.col); UP(D.P_ptr, L.P.ptr); UP(D.P_col, L.P.col); UP(D.R_ptr, L.R.ptr); UP(D.R_col, L.R.col); UP(D.r_to_p, L.r_to_p); }
+        UP(D.A_row, rows_of(L.A)); UP(D.diag, L.diag);
+        UP(D.P_row, rows_of(L.P)); UP(D.p_self, L.p_self);
         UP(D.ps_ptr, L.p_src.ptr); UP(D.ps_x, L.p_src.x); UP(D.ps_y, L.p_src.y);
-        UP(D.R_ptr, L.R.ptr); UP(D.R_col, L.R.col); UP(D.r_to_p, L.r_to_p);
         { std::vector<int> inv(L.r_to_p.size()); for (size_t k = 0; k < inv.size(); ++k) inv[L.r_to_p[k]] = (int)k; UP(D.p_to_r, inv); }
-        UP(D.ts_ptr, L.t_src.ptr); UP(D.ts_x, L.t_src.x); UP(D.ts_y, L.t_src.y);
-        UP(D.as_ptr, L.a_src.ptr); UP(D.as_x, L.a_src.x); UP(D.as_y, L.a_src.y); UP(D.as_mirror, L.a_mirror);
-        { std::vector<int> up; for (int b = 0; b < (int)L.a_mirror.size(); ++b) if (L.a_mirror[b] < 0) up.push_back(b); D.n_upper = (int)up.size(); UP(D.as_upper, up); }
+        if (!D.products_dev) {       // the host built the two pair-list products (sharded runs, TSGO_HOST_PRODUCTS, a row too dense for the device tables)
+            D.nnzT = L.T.nnz(); D.nnzNext = (int)L.a_src.ptr.size() - 1;
+            D.pairs_T = (double)L.t_src.x.size() / std::max(1, D.nnzT); D.pairs_A = (double)L.a_src.x.size() / std::max<double>(1, (double)std::count(L.a_mirror.begin(), L.a_mirror.end(), -1));
+            UP(D.ts_ptr, L.t_src.ptr); UP(D.ts_x, L.t_src.x); UP(D.ts_y, L.t_src.y);
+            UP(D.as_ptr, L.a_src.ptr); UP(D.as_x, L.a_src.x); UP(D.as_y, L.a_src.y); UP(D.as_mirror, L.a_mirror);
+            { std::vector<int> up; for (int b = 0; b < (int)L.a_mirror.size(); ++b) if (L.a_mirror[b] < 0) up.push_back(b); D.n_upper = (int)up.size(); UP(D.as_upper, up); }
+        }
         if (int rc = upload_T(&D.rel, L.rel.data(), L.rel.size())) return rc;
         if (int rc = dalloc(&D.A, (size_t)D.nnzA * 9)) return rc;
         if (int rc = dalloc(&D.Dinv, (size_t)D.n * 9)) return rc;
@@ -394,20 +417,112 @@ template <typename T> struct Engine : IEngine {
         }
         return 0;
     }
+    // One level's two pair-list products on the device (tsgo_sym_kernels.h): T = A P with its lists, A' = R T (upper blocks
+    // listed, lower ones mirrored) with its lists; the pattern of A' goes back to the host builder, which needs it for the next
+    // level.  *accepted = false: a row was too dense for the LDS tables — the host builds this level's lists itself.
+    double ms_device_products = 0;
+    int run_device_products(int l, AmgLevel& L, BlockCsr& A_next, bool* accepted) {
+        *accepted = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        DevLevel<T>& D = lv[l];
+        UP(D.A_ptr, L.A.ptr); UP(D.A_col, L.A.col); UP(D.P_ptr, L.P.ptr); UP(D.P_col, L.P.col); UP(D.R_ptr, L.R.ptr); UP(D.R_col, L.R.col); UP(D.r_to_p, L.r_to_p);
+        D.patterns_up = true;
+        const int n = L.n, na = L.n_agg;
+        int *d = nullptr, *m = nullptr, *tptr = nullptr, *tpoff = nullptr, *flags = nullptr;
+        if (int rc = dalloc(&d, (size_t)std::max(n, na))) return rc;
+        if (int rc = dalloc(&m, (size_t)std::max(n, na))) return rc;
+        if (int rc = dalloc(&tptr, (size_t)n + 1)) return rc;
+        if (int rc = dalloc(&tpoff, (size_t)n + 1)) return rc;
+        if (int rc = dalloc(&flags, 4)) return rc;
+        if (int rc = fill_zero(flags, 4 * sizeof(int))) return rc;
+        int h3[3];
+        // ---- T = A P
+        hipLaunchKernelGGL((k_sym_count<0>), dim3(n), dim3(kSymWave), 0, stream, n, (const int*)D.A_ptr, (const int*)D.A_col, (const int*)D.P_ptr, (const int*)D.P_col, d, m, flags);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, n, (const int*)d, tptr);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, n, (const int*)m, tpoff);
+        HIP_OK(hipMemcpyAsync(&h3[0], tptr + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(&h3[1], tpoff + n, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(&h3[2], flags, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (h3[2]) return 0;                     // declined
+        const int nnzT = h3[0], pairsT = h3[1];
+        int* tcol = nullptr;
+        if (int rc = dalloc(&tcol, (size_t)nnzT)) return rc;
+        if (int rc = dalloc(&D.ts_ptr, (size_t)nnzT + 1)) return rc;
+        if (int rc = dalloc(&D.ts_x, (size_t)pairsT)) return rc;
+        if (int rc = dalloc(&D.ts_y, (size_t)pairsT)) return rc;
+        hipLaunchKernelGGL((k_sym_fill<0>), dim3(n), dim3(kSymWave), 0, stream, n, (const int*)D.A_ptr, (const int*)D.A_col, (const int*)nullptr, (const int*)D.P_ptr, (const int*)D.P_col,
+                           (const int*)tptr, (const int*)tpoff, tcol, D.ts_ptr, D.ts_x, D.ts_y, (int*)nullptr);
+        HIP_OK(hipMemcpyAsync(D.ts_ptr + nnzT, &pairsT, sizeof(int), hipMemcpyHostToDevice, stream));
+        // ---- A' = R T, upper blocks listed
+        int *zptr = nullptr, *zpoff = nullptr, *nup = nullptr, *uoff = nullptr;
+        if (int rc = dalloc(&zptr, (size_t)na + 1)) return rc;
+        if (int rc = dalloc(&zpoff, (size_t)na + 1)) return rc;
+        if (int rc = dalloc(&nup, (size_t)na)) return rc;
+        if (int rc = dalloc(&uoff, (size_t)na + 1)) return rc;
+        hipLaunchKernelGGL((k_sym_count<1>), dim3(na), dim3(kSymWave), 0, stream, na, (const int*)D.R_ptr, (const int*)D.R_col, (const int*)tptr, (const int*)tcol, d, m, flags + 1);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, na, (const int*)d, zptr);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, na, (const int*)m, zpoff);
+        HIP_OK(hipMemcpyAsync(&h3[0], zptr + na, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(&h3[1], zpoff + na, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(&h3[2], flags + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (h3[2]) { D.ts_ptr = D.ts_x = D.ts_y = nullptr; return 0; }       // declined (the slab bytes of T's lists are lost until the next structure)
+        const int nnzN = h3[0], pairsA = h3[1];
+        int* zcol = nullptr;
+        if (int rc = dalloc(&zcol, (size_t)nnzN)) return rc;
+        if (int rc = dalloc(&D.as_ptr, (size_t)nnzN + 1)) return rc;
+        if (int rc = dalloc(&D.as_x, (size_t)pairsA)) return rc;
+        if (int rc = dalloc(&D.as_y, (size_t)pairsA)) return rc;
+        if (int rc = dalloc(&D.as_mirror, (size_t)nnzN)) return rc;
+        if (int rc = dalloc(&D.as_upper, (size_t)nnzN)) return rc;
+        hipLaunchKernelGGL((k_sym_fill<1>), dim3(na), dim3(kSymWave), 0, stream, na, (const int*)D.R_ptr, (const int*)D.R_col, (const int*)D.r_to_p, (const int*)tptr, (const int*)tcol,
+                           (const int*)zptr, (const int*)zpoff, zcol, D.as_ptr, D.as_x, D.as_y, nup);
+        HIP_OK(hipMemcpyAsync(D.as_ptr + nnzN, &pairsA, sizeof(int), hipMemcpyHostToDevice, stream));
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, na, (const int*)nup, uoff);
+        hipLaunchKernelGGL(k_sym_mirror, dim3((na + 255) / 256), dim3(256), 0, stream, na, (const int*)zptr, (const int*)zcol, (const int*)uoff, D.as_mirror, D.as_upper, flags + 2);
+        A_next.n_rows = A_next.n_cols = na;
+        A_next.ptr.resize((size_t)na + 1); A_next.col.resize((size_t)nnzN);
+        HIP_OK(hipMemcpyAsync(A_next.ptr.data(), zptr, ((size_t)na + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
+        if (nnzN) HIP_OK(hipMemcpyAsync(A_next.col.data(), zcol, (size_t)nnzN * sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(&h3[0], uoff + na, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipMemcpyAsync(&h3[1], flags + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
+        HIP_OK(hipStreamSynchronize(stream));
+        if (h3[1]) return set_error(-2, "tsgo_set_graph: the Galerkin pattern is not structurally symmetric");
+        D.n_upper = h3[0]; D.nnzT = nnzT; D.nnzNext = nnzN;
+        D.pairs_T = (double)pairsT / std::max(1, nnzT); D.pairs_A = (double)pairsA / std::max(1, D.n_upper);
+        D.products_dev = true;
+        *accepted = true;
+        ms_device_products += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    }
     int upload_amg() {
         lv.assign(32, DevLevel<T>());            // host/amg.cpp never builds more levels than this; trimmed below
         size_t done = 0; bool schur_done = false;
+        ms_device_products = 0;
+        // whatever way this function is left, a builder that is waiting for its products is released (and builds them itself)
+        struct CloseProducts { Engine* e; ~CloseProducts() { { std::lock_guard<std::mutex> l(e->amg_mu); e->products_open = false; } e->amg_cv.notify_all(); } } close_products{this};
         if (pr.world == 1) {                     // consume what the builder has finished while it works on the rest
             for (;;) {
-                int ready; bool schur, fin;
+                int ready; bool schur, fin, want_products;
                 {
                     std::unique_lock<std::mutex> l(amg_mu);
-                    amg_cv.wait(l, [&] { return amg_finished || (int)done < amg_levels_ready || (!schur_done && amg_schur_ready); });
-                    ready = amg_levels_ready; schur = amg_schur_ready; fin = amg_finished;
+                    amg_cv.wait(l, [&] { return amg_finished || (int)done < amg_levels_ready || (!schur_done && amg_schur_ready) || (preq.pending && !preq.done); });
+                    ready = amg_levels_ready; schur = amg_schur_ready; fin = amg_finished; want_products = preq.pending && !preq.done;
                 }
                 if (fin) break;                  // whatever is left is uploaded after the join (and errors are looked at there)
                 if (schur && !schur_done) { if (int rc = upload_schur_lists()) return rc; schur_done = true; }
                 for (; (int)done < ready; ++done) if (int rc = upload_level(done)) return rc;
+                if (want_products) {
+                    bool accepted = false;
+                    const int rc = (preq.level >= 0 && preq.level < (int)lv.size()) ? run_device_products(preq.level, *preq.L, *preq.A_next, &accepted) : 0;
+                    {
+                        std::lock_guard<std::mutex> l(amg_mu);
+                        preq.accepted = rc == 0 && accepted; preq.err = rc ? std::string(tsgo_last_error()) : std::string(); preq.done = true; preq.pending = false;
+                    }
+                    amg_cv.notify_all();
+                    if (rc) return rc;
+                }
             }
         }
         if (amg_builder.joinable()) amg_builder.join();
@@ -588,7 +703,9 @@ template <typename T> struct Engine : IEngine {
         if (P == 0) return set_error(-2, "tsgo_set_graph: the graph has no Se2 vertex");
         amg_on = cfg.preconditioner == 1 && pr.P > kCoarsestMax;
         if (amg_on) start_amg_builder(g);
-        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{amg_builder};   // on every error path too
+        // on every error path too: a builder that waits for its device products is told that nobody will serve them (it then builds
+        // them itself and ends), and is joined
+        struct Joiner { Engine* e; ~Joiner() { { std::lock_guard<std::mutex> l(e->amg_mu); e->products_open = false; } e->amg_cv.notify_all(); if (e->amg_builder.joinable()) e->amg_builder.join(); } } joiner{this};
         if (int rc = dalloc(&ps, (size_t)P * 4)) return rc;
         if (int rc = dalloc(&theta, (size_t)P)) return rc;
         if (int rc = dalloc(&lmrec, (size_t)std::max(L, 1) * kLmRec)) return rc;
@@ -633,7 +750,7 @@ template <typename T> struct Engine : IEngine {
         if (amg_on) { if (int rc = upload_amg()) return rc; }
         if (int rc = reset_solver_state()) return rc;
         HIP_OK(hipStreamSynchronize(stream));
-        if (say) std::fprintf(stderr, "[tsgo] set_graph:   of which multigrid patterns on the host %8.1f ms\n", ms_amg_symbolic);
+        if (say) std::fprintf(stderr, "[tsgo] set_graph:   of which multigrid patterns on the host %8.1f ms (its pair-list products on the device: %.1f ms of that)\n", ms_amg_symbolic, ms_device_products);
         if (say) for (size_t l = 0; l < lv.size(); ++l)
             std::fprintf(stderr, "[tsgo] level %zu: %d rows, %d blocks; pairs per block: A*P %.1f (%d blocks), P^T(AP) %.1f (%d upper blocks)\n", l, lv[l].n, lv[l].nnzA,
                          lv[l].pairs_T, lv[l].nnzT, lv[l].pairs_A, lv[l].n_upper);

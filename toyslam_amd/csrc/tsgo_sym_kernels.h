@@ -44,9 +44,10 @@ __device__ __forceinline__ int sym_insert(int* keys, int c, int* fresh) {
     *fresh = 0;
     return -1;
 }
+// slot of a column that IS in the table (every caller looks up what it inserted); bounded all the same: a wave must never spin
 __device__ __forceinline__ int sym_find(const int* keys, int c) {
     uint32_t h = sym_hash(c);
-    while (keys[h] != c) h = (h + 1) & (kSymTable - 1);
+    for (int probe = 0; probe < kSymTable && keys[h] != c; ++probe) h = (h + 1) & (kSymTable - 1);
     return (int)h;
 }
 __device__ __forceinline__ int sym_wave_sum(int v) {

@@ -415,12 +415,42 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
         }
     }, 4096);
     sw.lap("landmark observers");
-    struct Tup { int k; uint32_t a, b; int kind; };            // kind 0: landmark pair, 1: odom slot
-    struct SOut { std::vector<int> row_nnz, col, n_pair, n_od; std::vector<uint32_t> si, sk, os; };
     AmgLevel L0;
     L0.n = P;
     L0.A.n_rows = L0.A.n_cols = P;
-    {
+    bool schur_elsewhere = false;
+    if (progress && progress->schur) {
+        // the same inputs as CSR lists, laid out in parallel, for a builder that is not this one (the device)
+        SchurCsr in; in.P = P; in.L = pr.L; in.max_pair_degree = kMaxPairDegree;
+        in.pp_ptr.assign(P + 1, 0); in.od_ptr.assign(P + 1, 0);
+        parallel_chunks(P, [&](int, int b, int e) {
+            for (int i = b; i < e; ++i) {
+                int n = 0, no = 0;
+                for_slots(pr.by_pose, i, [&](size_t) { ++n; });
+                for_slots(pr.odom, i, [&](size_t k) { if ((int)(pr.odom.idx[k] & ~kDirBit) != i) ++no; });
+                in.pp_ptr[i + 1] = n; in.od_ptr[i + 1] = no;
+            }
+        }, 4096);
+        for (int i = 0; i < P; ++i) { in.pp_ptr[i + 1] += in.pp_ptr[i]; in.od_ptr[i + 1] += in.od_ptr[i]; }
+        in.pp_lm.resize((size_t)in.pp_ptr[P]); in.pp_slot.resize((size_t)in.pp_ptr[P]);
+        in.od_col.resize((size_t)in.od_ptr[P]); in.od_slot.resize((size_t)in.od_ptr[P]);
+        parallel_chunks(P, [&](int, int b, int e) {
+            for (int i = b; i < e; ++i) {
+                int at = in.pp_ptr[i], ao = in.od_ptr[i];
+                for_slots(pr.by_pose, i, [&](size_t k) { in.pp_lm[at] = (int)pr.by_pose.idx[k]; in.pp_slot[at] = (uint32_t)k; ++at; });
+                for_slots(pr.odom, i, [&](size_t k) { const int j = (int)(pr.odom.idx[k] & ~kDirBit); if (j != i) { in.od_col[ao] = j; in.od_slot[ao] = (uint32_t)k; ++ao; } });
+            }
+        }, 4096);
+        in.obs_ptr = std::move(obs_ptr); in.obs_pose = std::move(obs_pose); in.obs_slot = std::move(obs_slot);
+        std::string herr;
+        schur_elsewhere = progress->schur(in, L0.A, S.schur.ptr, S.schur.od_ptr, herr);
+        if (!herr.empty()) return herr;
+        if (!schur_elsewhere) { obs_ptr = std::move(in.obs_ptr); obs_pose = std::move(in.obs_pose); obs_slot = std::move(in.obs_slot); }
+        else { L0.A.n_rows = L0.A.n_cols = P; sw.lap("S pattern + lists (device)"); }
+    }
+    struct Tup { int k; uint32_t a, b; int kind; };            // kind 0: landmark pair, 1: odom slot
+    struct SOut { std::vector<int> row_nnz, col, n_pair, n_od; std::vector<uint32_t> si, sk, os; };
+    if (!schur_elsewhere) {
         std::vector<SOut> parts(64);
         const int used = parallel_chunks(P, [&](int c, int b, int e) {
             std::vector<Tup> row;
@@ -482,7 +512,7 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
             }
         }, 1);
     }
-    sw.lap("S pattern + lists");
+    if (!schur_elsewhere) sw.lap("S pattern + lists");
     if (progress && progress->schur_ready) progress->schur_ready();
 
     // ---- hierarchy ----------------------------------------------------------------------------------------

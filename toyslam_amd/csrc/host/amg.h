@@ -102,7 +102,20 @@ struct AmgSym {
 // Progress of build_amg, for a caller that wants to consume (upload) finished parts while the rest is being built:
 // schur_ready() once out.schur and out.order are final; level_ready(n) when out.levels[0 .. n-1] are final (the vector
 // never reallocates); both are called on the building thread.
+// Level 0's inputs as three CSR lists (what a device builder of the Schur pattern reads): a pose's LM edges (landmark, by_pose slot),
+// a landmark's observers (pose, by_pose slot of that edge), a pose's odometry slots (other pose, odom-table slot).
+struct SchurCsr {
+    int P = 0, L = 0, max_pair_degree = 0;
+    std::vector<int> pp_ptr, pp_lm; std::vector<uint32_t> pp_slot;
+    std::vector<int> obs_ptr, obs_pose; std::vector<uint32_t> obs_slot;
+    std::vector<int> od_ptr, od_col; std::vector<uint32_t> od_slot;
+};
+
 struct AmgProgress {
+    // Optional: level 0's pattern and contribution lists built by somebody else (the engine: tsgo_sym_kernels.h, k_s0_*).  True:
+    // A0 holds the pattern of S, sc_ptr / sc_od_ptr the list offsets per block (their differences are the coupling weights the
+    // aggregation needs); the lists themselves stay where they were built (SchurLists::slot_i, slot_k, od_slot remain empty).
+    std::function<bool(const SchurCsr& in, BlockCsr& A0, std::vector<int>& sc_ptr, std::vector<int>& sc_od_ptr, std::string& err)> schur;
     std::function<void()> schur_ready;
     std::function<void(int)> level_ready;
     // Optional: the two pair-list products of a level (T = A P and A' = P^T T) built by somebody else — the engine builds them on

@@ -116,6 +116,10 @@ struct tsgo_local_group {
 
 namespace {
 
+// The multigrid pattern builder runs on a thread of its own and does its device work (symbolic products) on a stream of its own:
+// the helpers below use the calling thread's stream, which is this one on the builder thread and the engine's elsewhere.
+thread_local hipStream_t t_builder_stream = nullptr;
+
 struct IEngine {
     virtual ~IEngine() {}
     virtual int set_graph(const tsgo_graph& g) = 0;
@@ -173,7 +177,9 @@ template <typename T> struct DevLevel {      // device copy of one AmgLevel (hos
 template <typename T> struct Engine : IEngine {
     tsgo_config cfg;
     Problem pr;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr, stream2 = nullptr;     // stream2: the pattern builder thread's
+    hipStream_t cs() const { return t_builder_stream ? t_builder_stream : stream; }
+    std::mutex slab_mu;                                    // the slab allocator is shared by the two threads of tsgo_set_graph
     // Device memory of a graph is bump-allocated from a few large slabs that the handle keeps: tsgo_set_graph with a new
     // structure frees nothing and allocates nothing as long as the new graph fits in what an earlier one needed (hipFree is
     // synchronous and a request makes ~230 allocations).  Slabs grow geometrically (64 MB ... 1 GB each) and are returned
@@ -256,7 +262,7 @@ template <typename T> struct Engine : IEngine {
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
 
-    ~Engine() override { release(); for (Slab& sl : slabs) (void)hipFree(sl.base); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); for (auto& e : ev) if (e) (void)hipEventDestroy(e); for (auto& m : prof) (void)hipEventDestroy(m.e); }
+    ~Engine() override { release(); for (Slab& sl : slabs) (void)hipFree(sl.base); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); if (stream2) (void)hipStreamDestroy(stream2); for (auto& e : ev) if (e) (void)hipEventDestroy(e); for (auto& m : prof) (void)hipEventDestroy(m.e); }
 
     void release() {
         if (amg_builder.joinable()) amg_builder.join();
@@ -280,6 +286,7 @@ template <typename T> struct Engine : IEngine {
     int init() {
         HIP_OK(hipSetDevice(cfg.device));
         HIP_OK(hipStreamCreateWithFlags(&stream, hipStreamNonBlocking));
+        HIP_OK(hipStreamCreateWithFlags(&stream2, hipStreamNonBlocking));
         for (auto& e : ev) HIP_OK(hipEventCreate(&e));
         return 0;
     }
@@ -289,12 +296,13 @@ template <typename T> struct Engine : IEngine {
     // requests from different threads of one process, and a legacy-stream call in one thread is refused by the runtime
     // while another thread captures a graph.
     int copy_sync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind) {
-        HIP_OK(hipMemcpyAsync(dst, src, bytes, kind, stream));
-        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipMemcpyAsync(dst, src, bytes, kind, cs()));
+        HIP_OK(hipStreamSynchronize(cs()));
         return 0;
     }
-    int fill_zero(void* dst, size_t bytes) { HIP_OK(hipMemsetAsync(dst, 0, bytes, stream)); return 0; }
+    int fill_zero(void* dst, size_t bytes) { HIP_OK(hipMemsetAsync(dst, 0, bytes, cs())); return 0; }
     template <typename U> int dalloc(U** out, size_t n) {
+        std::lock_guard<std::mutex> guard(slab_mu);
         const size_t bytes = (std::max<size_t>(n, 1) * sizeof(U) + 255) & ~size_t(255);
         for (Slab& sl : slabs)
             if (sl.used + bytes <= sl.cap) { *out = (U*)(sl.base + sl.used); sl.used += bytes; return 0; }
@@ -340,31 +348,32 @@ template <typename T> struct Engine : IEngine {
     std::string amg_builder_error;
     std::mutex amg_mu; std::condition_variable amg_cv;
     bool amg_schur_ready = false, amg_finished = false; int amg_levels_ready = 0;
-    // The builder thread asks the calling thread (the only one that touches the device and the slab allocator) to build a level's
-    // two pair-list products on the device, and waits for the next matrix's pattern (AmgProgress::products).
-    struct ProductRequest { int level = -1; AmgLevel* L = nullptr; BlockCsr* A_next = nullptr; bool pending = false, done = false, accepted = false; std::string err; } preq;
-    bool products_open = false;      // false: nobody is (any longer) serving requests — the builder does the products itself
     bool device_products = true;     // research switch TSGO_HOST_PRODUCTS=1: every pair list on the host, as rounds 1-2
     void start_amg_builder(const tsgo_graph& g) {
         amg_schur_ready = amg_finished = false; amg_levels_ready = 0;
-        preq = ProductRequest(); products_open = device_products && pr.world == 1;
         amg_builder = std::thread([this, &g] {      // g is borrowed for the whole tsgo_set_graph call, which joins this thread
             const auto t0 = std::chrono::steady_clock::now();
+            (void)hipSetDevice(cfg.device);
+            t_builder_stream = stream2;
             AmgProgress pg;
             pg.schur_ready = [this] { { std::lock_guard<std::mutex> l(amg_mu); amg_schur_ready = true; } amg_cv.notify_all(); };
             pg.level_ready = [this](int n) { { std::lock_guard<std::mutex> l(amg_mu); amg_levels_ready = n; } amg_cv.notify_all(); };
-            pg.products = [this](int level, AmgLevel& L, BlockCsr& A_next, std::string& err) -> bool {
-                std::unique_lock<std::mutex> l(amg_mu);
-                if (!products_open) return false;
-                preq.level = level; preq.L = &L; preq.A_next = &A_next; preq.pending = true; preq.done = false; preq.accepted = false; preq.err.clear();
-                amg_cv.notify_all();
-                amg_cv.wait(l, [&] { return preq.done || !products_open; });
-                if (!preq.done) { preq.pending = false; return false; }        // the server of requests has left (an error on its side): do it here
-                err = preq.err;
-                return preq.accepted;
-            };
+            if (device_products && pr.world == 1)
+                pg.schur = [this](const SchurCsr& in, BlockCsr& A0, std::vector<int>& sc_ptr_h, std::vector<int>& sc_od_ptr_h, std::string& err) -> bool {
+                    bool accepted = false;
+                    if (run_device_schur(in, A0, sc_ptr_h, sc_od_ptr_h, &accepted)) { err = last_error(); return false; }
+                    return accepted;
+                };
+            if (device_products && pr.world == 1)
+                pg.products = [this](int level, AmgLevel& L, BlockCsr& A_next, std::string& err) -> bool {       // on THIS thread, on its own stream
+                    bool accepted = false;
+                    if (level < 0 || level >= (int)lv.size()) return false;
+                    if (run_device_products(level, L, A_next, &accepted)) { err = last_error(); return false; }
+                    return accepted;
+                };
             amg_builder_error = pr.world > 1 ? build_amg_sharded(g, pr, amg) : build_amg(pr, amg, &pg);
             ms_amg_symbolic = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            t_builder_stream = nullptr;
             { std::lock_guard<std::mutex> l(amg_mu); amg_finished = true; }
             amg_cv.notify_all();
         });
@@ -375,7 +384,9 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
 #define UP(dst, vec) if (int rc = upload_i32(&dst, vec)) return rc
+    bool schur_dev = false;      // level 0's pattern and contribution lists were built on the device (run_device_schur)
     int upload_schur_lists() {
+        if (schur_dev) return 0;
         UP(sc_ptr, amg.schur.ptr); UP(sc_optr, amg.schur.od_ptr);
         if (int rc = upload_u32m(&sc_si, amg.schur.slot_i)) return rc;
         if (int rc = upload_u32m(&sc_sk, amg.schur.slot_k)) return rc;
@@ -417,6 +428,64 @@ template <typename T> struct Engine : IEngine {
         }
         return 0;
     }
+    // Level 0 on the device (tsgo_sym_kernels.h: k_s0_count / k_s0_fill): the pattern of the explicit Schur complement and, per block, the
+    // pairs of LM-edge slots and the odometry slots it is summed from.  The pattern and the list offsets go back to the host builder (the
+    // aggregation weighs a coupling by its number of contributions); the lists stay here.
+    int run_device_schur(const SchurCsr& in, BlockCsr& A0, std::vector<int>& sc_ptr_h, std::vector<int>& sc_od_ptr_h, bool* accepted) {
+        *accepted = false;
+        const auto t0 = std::chrono::steady_clock::now();
+        const int P = in.P;
+        int *pp_ptr, *pp_lm, *obs_ptr, *obs_pose, *od_ptr, *od_col; uint32_t *pp_slot, *obs_slot, *od_slot;
+        UP(pp_ptr, in.pp_ptr); UP(pp_lm, in.pp_lm); UP(obs_ptr, in.obs_ptr); UP(obs_pose, in.obs_pose); UP(od_ptr, in.od_ptr); UP(od_col, in.od_col);
+        if (int rc = upload_u32m(&pp_slot, in.pp_slot)) return rc;
+        if (int rc = upload_u32m(&obs_slot, in.obs_slot)) return rc;
+        if (int rc = upload_u32m(&od_slot, in.od_slot)) return rc;
+        int *d, *m, *mo, *zptr, *poff, *ooff, *flags;
+        if (int rc = dalloc(&d, (size_t)P)) return rc;
+        if (int rc = dalloc(&m, (size_t)P)) return rc;
+        if (int rc = dalloc(&mo, (size_t)P)) return rc;
+        if (int rc = dalloc(&zptr, (size_t)P + 1)) return rc;
+        if (int rc = dalloc(&poff, (size_t)P + 1)) return rc;
+        if (int rc = dalloc(&ooff, (size_t)P + 1)) return rc;
+        if (int rc = dalloc(&flags, 4)) return rc;
+        if (int rc = fill_zero(flags, 4 * sizeof(int))) return rc;
+        hipLaunchKernelGGL(k_s0_count, dim3(P), dim3(kSymWave), 0, cs(), P, (const int*)pp_ptr, (const int*)pp_lm, (const int*)obs_ptr, (const int*)obs_pose, (const int*)od_ptr,
+                           (const int*)od_col, in.max_pair_degree, d, m, mo, flags);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), P, (const int*)d, zptr);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), P, (const int*)m, poff);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), P, (const int*)mo, ooff);
+        int h4[4];
+        HIP_OK(hipMemcpyAsync(&h4[0], zptr + P, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(&h4[1], poff + P, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(&h4[2], ooff + P, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(&h4[3], flags, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipStreamSynchronize(cs()));
+        if (h4[3]) return 0;                     // a pose couples to too many others for the LDS tables: the host builds level 0
+        const int nnz = h4[0], n_pairs = h4[1], n_od = h4[2];
+        int* zcol = nullptr;
+        if (int rc = dalloc(&zcol, (size_t)nnz)) return rc;
+        if (int rc = dalloc(&sc_ptr, (size_t)nnz + 1)) return rc;
+        if (int rc = dalloc(&sc_optr, (size_t)nnz + 1)) return rc;
+        if (int rc = dalloc(&sc_si, (size_t)n_pairs)) return rc;
+        if (int rc = dalloc(&sc_sk, (size_t)n_pairs)) return rc;
+        if (int rc = dalloc(&sc_os, (size_t)n_od)) return rc;
+        hipLaunchKernelGGL(k_s0_fill, dim3(P), dim3(kSymWave), 0, cs(), P, (const int*)pp_ptr, (const int*)pp_lm, (const uint32_t*)pp_slot, (const int*)obs_ptr, (const int*)obs_pose,
+                           (const uint32_t*)obs_slot, (const int*)od_ptr, (const int*)od_col, (const uint32_t*)od_slot, in.max_pair_degree, (const int*)zptr, (const int*)poff,
+                           (const int*)ooff, zcol, sc_ptr, sc_optr, sc_si, sc_sk, sc_os);
+        HIP_OK(hipMemcpyAsync(sc_ptr + nnz, &n_pairs, sizeof(int), hipMemcpyHostToDevice, cs()));
+        HIP_OK(hipMemcpyAsync(sc_optr + nnz, &n_od, sizeof(int), hipMemcpyHostToDevice, cs()));
+        A0.n_rows = A0.n_cols = P;
+        A0.ptr.resize((size_t)P + 1); A0.col.resize((size_t)nnz); sc_ptr_h.resize((size_t)nnz + 1); sc_od_ptr_h.resize((size_t)nnz + 1);
+        HIP_OK(hipMemcpyAsync(A0.ptr.data(), zptr, ((size_t)P + 1) * sizeof(int), hipMemcpyDeviceToHost, cs()));
+        if (nnz) HIP_OK(hipMemcpyAsync(A0.col.data(), zcol, (size_t)nnz * sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(sc_ptr_h.data(), sc_ptr, ((size_t)nnz + 1) * sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(sc_od_ptr_h.data(), sc_optr, ((size_t)nnz + 1) * sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipStreamSynchronize(cs()));
+        schur_dev = true;
+        *accepted = true;
+        ms_device_products += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return 0;
+    }
     // One level's two pair-list products on the device (tsgo_sym_kernels.h): T = A P with its lists, A' = R T (upper blocks
     // listed, lower ones mirrored) with its lists; the pattern of A' goes back to the host builder, which needs it for the next
     // level.  *accepted = false: a row was too dense for the LDS tables — the host builds this level's lists itself.
@@ -437,13 +506,13 @@ template <typename T> struct Engine : IEngine {
         if (int rc = fill_zero(flags, 4 * sizeof(int))) return rc;
         int h3[3];
         // ---- T = A P
-        hipLaunchKernelGGL((k_sym_count<0>), dim3(n), dim3(kSymWave), 0, stream, n, (const int*)D.A_ptr, (const int*)D.A_col, (const int*)D.P_ptr, (const int*)D.P_col, d, m, flags);
-        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, n, (const int*)d, tptr);
-        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, n, (const int*)m, tpoff);
-        HIP_OK(hipMemcpyAsync(&h3[0], tptr + n, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipMemcpyAsync(&h3[1], tpoff + n, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipMemcpyAsync(&h3[2], flags, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipStreamSynchronize(stream));
+        hipLaunchKernelGGL((k_sym_count<0>), dim3(n), dim3(kSymWave), 0, cs(), n, (const int*)D.A_ptr, (const int*)D.A_col, (const int*)D.P_ptr, (const int*)D.P_col, d, m, flags);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), n, (const int*)d, tptr);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), n, (const int*)m, tpoff);
+        HIP_OK(hipMemcpyAsync(&h3[0], tptr + n, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(&h3[1], tpoff + n, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(&h3[2], flags, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipStreamSynchronize(cs()));
         if (h3[2]) return 0;                     // declined
         const int nnzT = h3[0], pairsT = h3[1];
         int* tcol = nullptr;
@@ -451,22 +520,22 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&D.ts_ptr, (size_t)nnzT + 1)) return rc;
         if (int rc = dalloc(&D.ts_x, (size_t)pairsT)) return rc;
         if (int rc = dalloc(&D.ts_y, (size_t)pairsT)) return rc;
-        hipLaunchKernelGGL((k_sym_fill<0>), dim3(n), dim3(kSymWave), 0, stream, n, (const int*)D.A_ptr, (const int*)D.A_col, (const int*)nullptr, (const int*)D.P_ptr, (const int*)D.P_col,
+        hipLaunchKernelGGL((k_sym_fill<0>), dim3(n), dim3(kSymWave), 0, cs(), n, (const int*)D.A_ptr, (const int*)D.A_col, (const int*)nullptr, (const int*)D.P_ptr, (const int*)D.P_col,
                            (const int*)tptr, (const int*)tpoff, tcol, D.ts_ptr, D.ts_x, D.ts_y, (int*)nullptr);
-        HIP_OK(hipMemcpyAsync(D.ts_ptr + nnzT, &pairsT, sizeof(int), hipMemcpyHostToDevice, stream));
+        HIP_OK(hipMemcpyAsync(D.ts_ptr + nnzT, &pairsT, sizeof(int), hipMemcpyHostToDevice, cs()));
         // ---- A' = R T, upper blocks listed
         int *zptr = nullptr, *zpoff = nullptr, *nup = nullptr, *uoff = nullptr;
         if (int rc = dalloc(&zptr, (size_t)na + 1)) return rc;
         if (int rc = dalloc(&zpoff, (size_t)na + 1)) return rc;
         if (int rc = dalloc(&nup, (size_t)na)) return rc;
         if (int rc = dalloc(&uoff, (size_t)na + 1)) return rc;
-        hipLaunchKernelGGL((k_sym_count<1>), dim3(na), dim3(kSymWave), 0, stream, na, (const int*)D.R_ptr, (const int*)D.R_col, (const int*)tptr, (const int*)tcol, d, m, flags + 1);
-        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, na, (const int*)d, zptr);
-        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, na, (const int*)m, zpoff);
-        HIP_OK(hipMemcpyAsync(&h3[0], zptr + na, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipMemcpyAsync(&h3[1], zpoff + na, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipMemcpyAsync(&h3[2], flags + 1, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipStreamSynchronize(stream));
+        hipLaunchKernelGGL((k_sym_count<1>), dim3(na), dim3(kSymWave), 0, cs(), na, (const int*)D.R_ptr, (const int*)D.R_col, (const int*)tptr, (const int*)tcol, d, m, flags + 1);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), na, (const int*)d, zptr);
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), na, (const int*)m, zpoff);
+        HIP_OK(hipMemcpyAsync(&h3[0], zptr + na, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(&h3[1], zpoff + na, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(&h3[2], flags + 1, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipStreamSynchronize(cs()));
         if (h3[2]) { D.ts_ptr = D.ts_x = D.ts_y = nullptr; return 0; }       // declined (the slab bytes of T's lists are lost until the next structure)
         const int nnzN = h3[0], pairsA = h3[1];
         int* zcol = nullptr;
@@ -476,18 +545,18 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&D.as_y, (size_t)pairsA)) return rc;
         if (int rc = dalloc(&D.as_mirror, (size_t)nnzN)) return rc;
         if (int rc = dalloc(&D.as_upper, (size_t)nnzN)) return rc;
-        hipLaunchKernelGGL((k_sym_fill<1>), dim3(na), dim3(kSymWave), 0, stream, na, (const int*)D.R_ptr, (const int*)D.R_col, (const int*)D.r_to_p, (const int*)tptr, (const int*)tcol,
+        hipLaunchKernelGGL((k_sym_fill<1>), dim3(na), dim3(kSymWave), 0, cs(), na, (const int*)D.R_ptr, (const int*)D.R_col, (const int*)D.r_to_p, (const int*)tptr, (const int*)tcol,
                            (const int*)zptr, (const int*)zpoff, zcol, D.as_ptr, D.as_x, D.as_y, nup);
-        HIP_OK(hipMemcpyAsync(D.as_ptr + nnzN, &pairsA, sizeof(int), hipMemcpyHostToDevice, stream));
-        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, stream, na, (const int*)nup, uoff);
-        hipLaunchKernelGGL(k_sym_mirror, dim3((na + 255) / 256), dim3(256), 0, stream, na, (const int*)zptr, (const int*)zcol, (const int*)uoff, D.as_mirror, D.as_upper, flags + 2);
+        HIP_OK(hipMemcpyAsync(D.as_ptr + nnzN, &pairsA, sizeof(int), hipMemcpyHostToDevice, cs()));
+        hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), na, (const int*)nup, uoff);
+        hipLaunchKernelGGL(k_sym_mirror, dim3((na + 255) / 256), dim3(256), 0, cs(), na, (const int*)zptr, (const int*)zcol, (const int*)uoff, D.as_mirror, D.as_upper, flags + 2);
         A_next.n_rows = A_next.n_cols = na;
         A_next.ptr.resize((size_t)na + 1); A_next.col.resize((size_t)nnzN);
-        HIP_OK(hipMemcpyAsync(A_next.ptr.data(), zptr, ((size_t)na + 1) * sizeof(int), hipMemcpyDeviceToHost, stream));
-        if (nnzN) HIP_OK(hipMemcpyAsync(A_next.col.data(), zcol, (size_t)nnzN * sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipMemcpyAsync(&h3[0], uoff + na, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipMemcpyAsync(&h3[1], flags + 2, sizeof(int), hipMemcpyDeviceToHost, stream));
-        HIP_OK(hipStreamSynchronize(stream));
+        HIP_OK(hipMemcpyAsync(A_next.ptr.data(), zptr, ((size_t)na + 1) * sizeof(int), hipMemcpyDeviceToHost, cs()));
+        if (nnzN) HIP_OK(hipMemcpyAsync(A_next.col.data(), zcol, (size_t)nnzN * sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(&h3[0], uoff + na, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipMemcpyAsync(&h3[1], flags + 2, sizeof(int), hipMemcpyDeviceToHost, cs()));
+        HIP_OK(hipStreamSynchronize(cs()));
         if (h3[1]) return set_error(-2, "tsgo_set_graph: the Galerkin pattern is not structurally symmetric");
         D.n_upper = h3[0]; D.nnzT = nnzT; D.nnzNext = nnzN;
         D.pairs_T = (double)pairsT / std::max(1, nnzT); D.pairs_A = (double)pairsA / std::max(1, D.n_upper);
@@ -497,32 +566,18 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
     int upload_amg() {
-        lv.assign(32, DevLevel<T>());            // host/amg.cpp never builds more levels than this; trimmed below
         size_t done = 0; bool schur_done = false;
-        ms_device_products = 0;
-        // whatever way this function is left, a builder that is waiting for its products is released (and builds them itself)
-        struct CloseProducts { Engine* e; ~CloseProducts() { { std::lock_guard<std::mutex> l(e->amg_mu); e->products_open = false; } e->amg_cv.notify_all(); } } close_products{this};
         if (pr.world == 1) {                     // consume what the builder has finished while it works on the rest
             for (;;) {
-                int ready; bool schur, fin, want_products;
+                int ready; bool schur, fin;
                 {
                     std::unique_lock<std::mutex> l(amg_mu);
-                    amg_cv.wait(l, [&] { return amg_finished || (int)done < amg_levels_ready || (!schur_done && amg_schur_ready) || (preq.pending && !preq.done); });
-                    ready = amg_levels_ready; schur = amg_schur_ready; fin = amg_finished; want_products = preq.pending && !preq.done;
+                    amg_cv.wait(l, [&] { return amg_finished || (int)done < amg_levels_ready || (!schur_done && amg_schur_ready); });
+                    ready = amg_levels_ready; schur = amg_schur_ready; fin = amg_finished;
                 }
                 if (fin) break;                  // whatever is left is uploaded after the join (and errors are looked at there)
                 if (schur && !schur_done) { if (int rc = upload_schur_lists()) return rc; schur_done = true; }
                 for (; (int)done < ready; ++done) if (int rc = upload_level(done)) return rc;
-                if (want_products) {
-                    bool accepted = false;
-                    const int rc = (preq.level >= 0 && preq.level < (int)lv.size()) ? run_device_products(preq.level, *preq.L, *preq.A_next, &accepted) : 0;
-                    {
-                        std::lock_guard<std::mutex> l(amg_mu);
-                        preq.accepted = rc == 0 && accepted; preq.err = rc ? std::string(tsgo_last_error()) : std::string(); preq.done = true; preq.pending = false;
-                    }
-                    amg_cv.notify_all();
-                    if (rc) return rc;
-                }
             }
         }
         if (amg_builder.joinable()) amg_builder.join();
@@ -702,10 +757,10 @@ template <typename T> struct Engine : IEngine {
         const int P = pr.P, L = pr.L;
         if (P == 0) return set_error(-2, "tsgo_set_graph: the graph has no Se2 vertex");
         amg_on = cfg.preconditioner == 1 && pr.P > kCoarsestMax;
+        lv.assign(32, DevLevel<T>());            // host/amg.cpp never builds more levels than this; trimmed in upload_amg (the builder thread fills entries)
+        ms_device_products = 0; schur_dev = false;
         if (amg_on) start_amg_builder(g);
-        // on every error path too: a builder that waits for its device products is told that nobody will serve them (it then builds
-        // them itself and ends), and is joined
-        struct Joiner { Engine* e; ~Joiner() { { std::lock_guard<std::mutex> l(e->amg_mu); e->products_open = false; } e->amg_cv.notify_all(); if (e->amg_builder.joinable()) e->amg_builder.join(); } } joiner{this};
+        struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } joiner{amg_builder};   // on every error path too
         if (int rc = dalloc(&ps, (size_t)P * 4)) return rc;
         if (int rc = dalloc(&theta, (size_t)P)) return rc;
         if (int rc = dalloc(&lmrec, (size_t)std::max(L, 1) * kLmRec)) return rc;

@@ -201,3 +201,129 @@ __global__ __launch_bounds__(256) void k_sym_mirror(int n, const int* __restrict
 }
 
 }  // namespace tsgo
+
+// ---- level 0: pattern of the explicit Schur complement S and its contribution lists (host/amg.cpp: "S pattern + lists") ------------
+// Row i = pose i.  A block (i, k), k != i, exists when the poses share a landmark (seen from at most `max_deg` poses: hub landmarks
+// stay out of the preconditioner's explicit matrix) or an odometry edge; it is summed from pairs (slot of i's edge, slot of k's edge)
+// per shared landmark, and from the odometry slots of row i that lead to k.  The diagonal block always exists, with empty lists.
+// Inputs are three CSR lists the host lays out in parallel: a pose's LM edges (landmark, by_pose slot; slots ascending), a
+// landmark's observers (pose, by_pose slot of that edge), a pose's odometry slots (other pose, slot; slots ascending).
+// Lists come out sorted as the host sorts them: pairs by (slot of i, slot of k), odometry slots ascending.
+namespace tsgo {
+
+__global__ __launch_bounds__(kSymWave) void k_s0_count(int P, const int* __restrict__ pp_ptr, const int* __restrict__ pp_lm, const int* __restrict__ obs_ptr,
+                                                       const int* __restrict__ obs_pose, const int* __restrict__ od_ptr, const int* __restrict__ od_col,
+                                                       int max_deg, int* __restrict__ d, int* __restrict__ m, int* __restrict__ mo, int* __restrict__ overflow) {
+    __shared__ int keys[kSymTable];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= P) return;
+    for (int k = lane; k < kSymTable; k += kSymWave) keys[k] = -1;
+    __syncthreads();
+    int distinct = 0, pairs = 0, odn = 0, fresh;
+    if (lane == 0) { (void)sym_insert(keys, i, &fresh); distinct += fresh; }
+    for (int a = pp_ptr[i]; a < pp_ptr[i + 1]; ++a) {
+        const int l = pp_lm[a];
+        const int q0 = obs_ptr[l], q1 = obs_ptr[l + 1];
+        if (q1 - q0 > max_deg) continue;
+        for (int q = q0 + lane; q < q1; q += kSymWave) {
+            const int c = obs_pose[q];
+            if (c == i) continue;
+            if (sym_insert(keys, c, &fresh) < 0) *overflow = 1;
+            distinct += fresh; ++pairs;
+        }
+        if (sym_wave_sum(distinct) > kSymMaxDistinct) { if (lane == 0) *overflow = 1; return; }
+    }
+    for (int e = od_ptr[i] + lane; e < od_ptr[i + 1]; e += kSymWave) {
+        if (sym_insert(keys, od_col[e], &fresh) < 0) *overflow = 1;
+        distinct += fresh; ++odn;
+    }
+    distinct = sym_wave_sum(distinct); pairs = sym_wave_sum(pairs); odn = sym_wave_sum(odn);
+    if (lane == 0) { d[i] = distinct; m[i] = pairs; mo[i] = odn; }
+}
+
+__global__ __launch_bounds__(kSymWave) void k_s0_fill(int P, const int* __restrict__ pp_ptr, const int* __restrict__ pp_lm, const uint32_t* __restrict__ pp_slot,
+                                                      const int* __restrict__ obs_ptr, const int* __restrict__ obs_pose, const uint32_t* __restrict__ obs_slot,
+                                                      const int* __restrict__ od_ptr, const int* __restrict__ od_col, const uint32_t* __restrict__ od_slot, int max_deg,
+                                                      const int* __restrict__ zptr, const int* __restrict__ poff, const int* __restrict__ ooff, int* __restrict__ zcol,
+                                                      int* __restrict__ sc_ptr, int* __restrict__ sc_optr, uint32_t* __restrict__ slot_i, uint32_t* __restrict__ slot_k,
+                                                      uint32_t* __restrict__ os) {
+    __shared__ int keys[kSymTable], vals[kSymTable];
+    __shared__ int cols[kSymMaxDistinct], cnt[kSymMaxDistinct], cnt_od[kSymMaxDistinct];
+    __shared__ int n_cols;
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= P) return;
+    for (int k = lane; k < kSymTable; k += kSymWave) keys[k] = -1;
+    if (lane == 0) n_cols = 0;
+    __syncthreads();
+    int fresh;
+    if (lane == 0) { (void)sym_insert(keys, i, &fresh); if (fresh) cols[atomicAdd(&n_cols, 1)] = i; }
+    for (int a = pp_ptr[i]; a < pp_ptr[i + 1]; ++a) {
+        const int l = pp_lm[a];
+        const int q0 = obs_ptr[l], q1 = obs_ptr[l + 1];
+        if (q1 - q0 > max_deg) continue;
+        for (int q = q0 + lane; q < q1; q += kSymWave) {
+            const int c = obs_pose[q];
+            if (c == i) continue;
+            (void)sym_insert(keys, c, &fresh);
+            if (fresh) cols[atomicAdd(&n_cols, 1)] = c;
+        }
+    }
+    for (int e = od_ptr[i] + lane; e < od_ptr[i + 1]; e += kSymWave) {
+        (void)sym_insert(keys, od_col[e], &fresh);
+        if (fresh) cols[atomicAdd(&n_cols, 1)] = od_col[e];
+    }
+    __syncthreads();
+    const int dd = n_cols;
+    int size = 1; while (size < dd) size <<= 1;
+    for (int t = dd + lane; t < size; t += kSymWave) cols[t] = 0x7fffffff;
+    __syncthreads();
+    sym_sort(cols, size, lane);
+    const int z0 = zptr[i];
+    for (int r = lane; r < dd; r += kSymWave) { vals[sym_find(keys, cols[r])] = r; zcol[z0 + r] = cols[r]; cnt[r] = 0; cnt_od[r] = 0; }
+    __syncthreads();
+    for (int a = pp_ptr[i]; a < pp_ptr[i + 1]; ++a) {
+        const int l = pp_lm[a];
+        const int q0 = obs_ptr[l], q1 = obs_ptr[l + 1];
+        if (q1 - q0 > max_deg) continue;
+        for (int q = q0 + lane; q < q1; q += kSymWave) {
+            const int c = obs_pose[q];
+            if (c != i) atomicAdd(&cnt[vals[sym_find(keys, c)]], 1);
+        }
+    }
+    for (int e = od_ptr[i] + lane; e < od_ptr[i + 1]; e += kSymWave) atomicAdd(&cnt_od[vals[sym_find(keys, od_col[e])]], 1);
+    __syncthreads();
+    if (lane == 0) {
+        int run = poff[i], run_od = ooff[i];
+        for (int r = 0; r < dd; ++r) {
+            const int v = cnt[r], w = cnt_od[r];
+            sc_ptr[z0 + r] = run; cnt[r] = run; run += v;
+            sc_optr[z0 + r] = run_od; cnt_od[r] = run_od; run_od += w;
+        }
+    }
+    __syncthreads();
+    // pairs: one LM edge of pose i after the other (slots ascending).  Within one edge the observers that are the same pose (an edge
+    // given twice) must keep their order, so a lane that meets a column another lane of this trip also has waits for its turn:
+    // the trip is serialised over the lanes only in that (rare) case.
+    for (int a = pp_ptr[i]; a < pp_ptr[i + 1]; ++a) {
+        const int l = pp_lm[a];
+        const int q0 = obs_ptr[l], q1 = obs_ptr[l + 1];
+        if (q1 - q0 > max_deg) continue;
+        const uint32_t sa = pp_slot[a];
+        for (int base = q0; base < q1; base += kSymWave) {
+            const int q = base + lane;
+            const int c = q < q1 ? obs_pose[q] : i;
+            const int r = c != i ? vals[sym_find(keys, c)] : -1;
+            // rank of this lane among the earlier lanes of the trip with the same output block (0 unless the edge list repeats an edge)
+            int before = 0;
+            for (int o = 0; o < kSymWave; ++o) { const int ro = __shfl(r, o); if (o < lane && ro == r) ++before; }
+            if (r >= 0) { const int dst = cnt[r] + before; slot_i[dst] = sa; slot_k[dst] = obs_slot[q]; }
+            __syncthreads();
+            if (r >= 0) atomicAdd(&cnt[r], 1);
+            __syncthreads();
+        }
+    }
+    if (lane == 0)
+        for (int e = od_ptr[i]; e < od_ptr[i + 1]; ++e) { const int r = vals[sym_find(keys, od_col[e])]; os[cnt_od[r]++] = od_slot[e]; }
+}
+
+}  // namespace tsgo

@@ -384,7 +384,7 @@ int aggregate_by_matching(WGraph& g, std::vector<int>& key, int target, std::vec
 }  // namespace
 
 std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progress) {
-    if (pr.world != 1) return "the multigrid preconditioner is single-shard";
+    if (pr.world != 1) return "build_amg takes the WHOLE graph's layout (a shard goes through build_amg_sharded, which builds the whole graph's patterns and keeps its own contribution lists)";
     Stopwatch sw;
     out = AmgSym();
     AmgSym& S = out;

@@ -125,7 +125,7 @@ struct AmgProgress {
     std::function<bool(int level, AmgLevel& L, BlockCsr& A_next, std::string& err)> products;
 };
 
-// Builds the hierarchy for a single-shard problem INTO `out` (cleared first).  Returns "" or an error text.
+// Builds the hierarchy from the layout of a WHOLE graph (world = 1) INTO `out` (cleared first).  Returns "" or an error text.
 std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progress = nullptr);
 
 // Edge-sharded runs (Problem::world > 1): the hierarchy is REPLICATED — every rank builds the same patterns from the

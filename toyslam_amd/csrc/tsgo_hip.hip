@@ -224,7 +224,8 @@ template <typename T> struct Engine : IEngine {
     hipGraphExec_t cg_graph = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int predicted_cg = 0;
-    // multigrid preconditioner (single shard)
+    // multigrid preconditioner.  Edge-sharded runs use it too: every rank holds the whole hierarchy (patterns from the whole graph,
+    // level-0 blocks all-reduced, everything below computed redundantly); only the level-0 contribution lists are per shard
     bool amg_on = false;
     AmgSym amg;
     std::vector<DevLevel<T>> lv;

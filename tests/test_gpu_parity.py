@@ -466,6 +466,25 @@ def test_pair_lists_built_on_the_device_equal_the_hosts(monkeypatch, n_poses, lc
     np.testing.assert_array_equal(vd, vh)
 
 
+@pytest.mark.parametrize("bits", [1, 2, 4, 7])
+def test_device_pattern_builders_hand_back_to_the_host(monkeypatch, bits):
+    """A row with more distinct columns than the device builders' LDS tables hold (1 024) makes them decline: level 0, or a level's
+    two products, is then built by the host after all.  TSGO_SYM_DECLINE makes them decline on an ordinary graph (bit 1: level 0,
+    2: every T = A P, 4: A' = R T on the odd levels): whichever mix of builders, the same lists, the same bits."""
+    g = synth.make(6000, 10, loop_closures=60, seed=43)
+    res = []
+    for decline in (0, bits):
+        monkeypatch.setenv("TSGO_SYM_DECLINE", str(decline))
+        o = HipOptimizer(pcg_rel_tol=1e-12)
+        try:
+            o.set_graph(g); res.append((o.optimize(4), o.vertices()))
+        finally:
+            o.close()
+    np.testing.assert_array_equal(res[1][0]["chi2"], res[0][0]["chi2"])
+    np.testing.assert_array_equal(res[1][0]["cg_iters"], res[0][0]["cg_iters"])
+    np.testing.assert_array_equal(res[1][1], res[0][1])
+
+
 def test_rejects_bad_graphs_without_crashing(opt):
     g = util.tiny_arrays("tiny_a")
     bad = g.copy(); bad.e_ids[1, 1] = 999

@@ -259,6 +259,7 @@ template <typename T> struct Engine : IEngine {
         explicit0 = c.cycle_level0 != 0;
         cy16 = c.cycle_storage != 32;
         if (const char* e = getenv("TSGO_HOST_PRODUCTS")) device_products = atoi(e) == 0;
+        if (const char* e = getenv("TSGO_SYM_DECLINE")) sym_decline = atoi(e);
         if (const char* e = getenv("TSGO_HIER_MAX_AGE")) hier_max_age = std::max(1, atoi(e));
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
@@ -350,6 +351,8 @@ template <typename T> struct Engine : IEngine {
     std::mutex amg_mu; std::condition_variable amg_cv;
     bool amg_schur_ready = false, amg_finished = false; int amg_levels_ready = 0;
     bool device_products = true;     // research switch TSGO_HOST_PRODUCTS=1: every pair list on the host, as rounds 1-2
+    int sym_decline = 0;             // test hook TSGO_SYM_DECLINE (bits): the device builders behave as if a row had overflowed their LDS tables —
+                                     // 1: level 0, 2: T = A P of every level, 4: A' = R T of every odd level — so that the hand-back to the host runs
     void start_amg_builder(const tsgo_graph& g) {
         amg_schur_ready = amg_finished = false; amg_levels_ready = 0;
         amg_builder = std::thread([this, &g] {      // g is borrowed for the whole tsgo_set_graph call, which joins this thread
@@ -461,7 +464,7 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipMemcpyAsync(&h4[2], ooff + P, sizeof(int), hipMemcpyDeviceToHost, cs()));
         HIP_OK(hipMemcpyAsync(&h4[3], flags, sizeof(int), hipMemcpyDeviceToHost, cs()));
         HIP_OK(hipStreamSynchronize(cs()));
-        if (h4[3]) return 0;                     // a pose couples to too many others for the LDS tables: the host builds level 0
+        if (h4[3] || (sym_decline & 1)) return 0;      // a pose couples to too many others for the LDS tables: the host builds level 0
         const int nnz = h4[0], n_pairs = h4[1], n_od = h4[2];
         int* zcol = nullptr;
         if (int rc = dalloc(&zcol, (size_t)nnz)) return rc;
@@ -514,7 +517,7 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipMemcpyAsync(&h3[1], tpoff + n, sizeof(int), hipMemcpyDeviceToHost, cs()));
         HIP_OK(hipMemcpyAsync(&h3[2], flags, sizeof(int), hipMemcpyDeviceToHost, cs()));
         HIP_OK(hipStreamSynchronize(cs()));
-        if (h3[2]) return 0;                     // declined
+        if (h3[2] || (sym_decline & 2)) return 0;      // declined
         const int nnzT = h3[0], pairsT = h3[1];
         int* tcol = nullptr;
         if (int rc = dalloc(&tcol, (size_t)nnzT)) return rc;
@@ -537,7 +540,7 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipMemcpyAsync(&h3[1], zpoff + na, sizeof(int), hipMemcpyDeviceToHost, cs()));
         HIP_OK(hipMemcpyAsync(&h3[2], flags + 1, sizeof(int), hipMemcpyDeviceToHost, cs()));
         HIP_OK(hipStreamSynchronize(cs()));
-        if (h3[2]) { D.ts_ptr = D.ts_x = D.ts_y = nullptr; return 0; }       // declined (the slab bytes of T's lists are lost until the next structure)
+        if (h3[2] || ((sym_decline & 4) && (l & 1))) { D.ts_ptr = D.ts_x = D.ts_y = nullptr; return 0; }       // declined (the slab bytes of T's lists are lost until the next structure)
         const int nnzN = h3[0], pairsA = h3[1];
         int* zcol = nullptr;
         if (int rc = dalloc(&zcol, (size_t)nnzN)) return rc;

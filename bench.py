@@ -156,7 +156,7 @@ def main():
     opt = HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol,
                        rank=rank if shard else 0, world=world if shard else 1,
                        use_graphs=not ARGS.no_graphs, lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
-                       preconditioner=ARGS.precond, cycle_level0="explicit" if explicit_cycle else "implicit", cycle_storage=ARGS.cycle_storage)
+                       preconditioner=ARGS.precond, warm_start=ARGS.warm_start, cycle_level0="explicit" if explicit_cycle else "implicit", cycle_storage=ARGS.cycle_storage)
     if ARGS.force_collective and world == 1:          # research: the sharded code path (eager launches + RCCL calls) with a one-rank communicator
         with stdout_to_stderr():
             opt.comm_init(opt.comm_unique_id())
@@ -339,6 +339,7 @@ if __name__ == "__main__":
                     help="N > 1: keep the implicit (sharded, all-reduced) Schur products inside the multigrid cycle: three all-reduces per PCG iteration")
     ap.add_argument("--explicit-cycle", dest="explicit_cycle", action="store_true",
                     help="N = 1: tsgo_config.cycle_level0 = 1 (what N > 1 runs by default)")
+    ap.add_argument("--warm-start", dest="warm_start", type=int, default=None, help="tsgo_config.warm_start (research: 3 = third-order extrapolation)")
     ap.add_argument("--cycle-storage", dest="cycle_storage", type=int, default=16, choices=[16, 32],
                     help="tsgo_config.cycle_storage: the V-cycle's copies of the hierarchy as packed half floats (default) or f32")
     ap.add_argument("--force-collective", dest="force_collective", action="store_true",

@@ -65,9 +65,11 @@ typedef struct tsgo_config {
                                 patterns from the whole graph (host memory: a full-graph layout + the hierarchy on every rank), the level-0
                                 blocks are all-reduced (rank 0 contributes the diagonal), everything below is computed redundantly. */
     int32_t xcd_map;         /* 1: workgroup -> slice map gives each XCD a contiguous eighth of the vertices; 0: round-robin */
-    int32_t warm_start;      /* 0: PCG starts from zero.  1: from (1 - step) * the previous Gauss-Newton iteration's pose delta (the
-                                un-taken remainder of the last step).  2 (default): from the third solve on, extrapolated with the
-                                delta before that as well, (1 - step) * (2 d1 - (1 - step) d2).  Same answer to pcg_rel_tol. */
+    int32_t warm_start;      /* 0: PCG starts from zero.  m >= 1: from a prediction of this solve's pose delta made from the deltas of the last
+                                (up to m, at most 6) Gauss-Newton iterations: order 1 is (1 - step) * the previous delta (the un-taken
+                                remainder of the last step); order k continues the degree-(k-1) trend of delta_j / (1 - step)^j.  Below the
+                                cap the engine takes, solve by solve, the order that would have predicted the previous delta best.
+                                Default 6.  Same answer to pcg_rel_tol. */
     int32_t rules;           /* 0 (default): the loop of the C++ server, remote/optimizer/OptimizerCpu.h:80-180 (fixed step 0.2, plateau /
                                 short-step / getting-worse stops, b untouched at fixed vertices).  1: the loop of the reference's in-process
                                 Python optimizer, python/optimizer/graph_optimizer.py:20-92 — Levenberg-Marquardt-style damping H + lambda I

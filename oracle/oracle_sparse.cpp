@@ -22,6 +22,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <deque>
 #include <vector>
 
 #include "amg_twin.h"
@@ -566,7 +567,9 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
     if (precond == 1 && !tw.enable_amg(g).empty()) return -5;
     std::memcpy(v_pos_out, v_pos, sizeof(double) * 3 * (size_t)nV);
     double prevErr = -1; int penalty = 0;
-    std::vector<double> xprev, xprev2;
+    constexpr int kTwinMaxWarm = 6; constexpr double kTwinWarmMargin = 4;      // kMaxWarm, kWarmMargin of tsgo_kernels.h
+    std::deque<std::vector<double>> hist;      // pose deltas of the last solves, newest first
+    double warm_err[kTwinMaxWarm] = {}; int n_tested = 0;
     *stop_reason = 0; *iters_run = 0; *last_delta_norm = 0;
     if (seconds_lin) *seconds_lin = 0;
     if (seconds_solve) *seconds_solve = 0;
@@ -574,13 +577,23 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
     for (int it = 0; it < iterations; ++it) {
         double t0 = now();
         static const bool cold = getenv("TSGO_TWIN_COLD") != nullptr;
-        static const double ext = getenv("TSGO_TWIN_EXTRAP") ? atof(getenv("TSGO_TWIN_EXTRAP")) : 1.0;     // as Engine::launch_warm (tsgo_hip.hip)
+        // as Engine::launch_warm / k_pack_x (tsgo_hip.hip, tsgo_kernels.h): x0 = sum_j c[m][j] d_j, the continuation of the degree-(m-1)
+        // trend of d_j / a^j, at the order m (<= TSGO_TWIN_WARM, default 6) that would have predicted the last delta best
+        static const int warm_cap = getenv("TSGO_TWIN_WARM") ? atoi(getenv("TSGO_TWIN_WARM")) : 6;
         std::vector<double> xw;
-        if (it > 1 && ext != 0.0 && xprev2.size() == xprev.size()) {     // x0 = 0.8 (d1 + ext * (d1 - 0.8 d2)) after the 0.8 scaling inside linearize()
-            xw.resize(xprev.size());
-            for (size_t k = 0; k < xw.size(); ++k) xw[k] = xprev[k] + ext * (xprev[k] - (1.0 - tw.step) * xprev2[k]);
+        if (it > 0 && !cold && warm_cap > 0 && tw.step < 1.0) {      // a full step (lr = 1) leaves no remainder to start from
+            const double a = 1.0 - tw.step;
+            auto coeff = [&](int m, int j) { double binom = 1, apow = 1; for (int q = 1; q <= j; ++q) { binom = binom * (m - q + 1) / q; apow *= a; } return (j & 1 ? 1.0 : -1.0) * binom * apow; };   // j = 1..m
+            int m = 1;
+            const int n_max = std::max(1, std::min({(int)hist.size(), warm_cap, kTwinMaxWarm}));
+            if (n_tested > 0) {
+                double best = warm_err[0];
+                for (int j = 1; j < n_tested && j < n_max; ++j) if (warm_err[j] * kTwinWarmMargin < best) { best = warm_err[j]; m = j + 1; }
+            }
+            xw.assign(hist[0].size(), 0.0);
+            for (int j = 1; j <= m; ++j) { const double c = coeff(m, j) / a; for (size_t k = 0; k < xw.size(); ++k) xw[k] += c * hist[j - 1][k]; }   // linearize() scales by a
         }
-        const std::vector<double>* warm = it > 0 && !cold ? (xw.empty() ? &xprev : &xw) : nullptr;
+        const std::vector<double>* warm = xw.empty() ? nullptr : &xw;
         double gamma0;
         if (py) {          // as Engine::optimize: linearise with the lambda a non-increasing chi^2 gives, repeat when it did rise
             tw.lambda = std::max(lam / 1.1, 1e-6);
@@ -594,7 +607,20 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
         if (!py) { if (prevErr > 0 && err > prevErr) { if (++penalty > 2) { *stop_reason = 1; break; } } else penalty = 0; }
         bool ok; cg_trace[it] = tw.solve_with_fallback(gamma0, pcg_tol, max_cg, &ok);
         if (!ok) { *stop_reason = 4; break; }
-        xprev2 = xprev; xprev = tw.x;
+        {   // k_save_x: what every order would have made of predicting this delta from the ones before it
+            const double a = 1.0 - tw.step;
+            const int n_test = std::min({(int)hist.size(), warm_cap, kTwinMaxWarm - 1});
+            for (int m = 1; m <= n_test; ++m) {
+                double binom = 1, apow = 1; double c[kTwinMaxWarm];
+                for (int j = 1; j <= m; ++j) { binom = binom * (m - j + 1) / j; apow *= a; c[j - 1] = (j & 1 ? 1.0 : -1.0) * binom * apow; }
+                double e = 0;
+                for (size_t k = 0; k < tw.x.size(); ++k) { double p = 0; for (int j = 0; j < m; ++j) p += c[j] * hist[j][k]; e += (tw.x[k] - p) * (tw.x[k] - p); }
+                warm_err[m - 1] = e;
+            }
+            n_tested = n_test;
+            hist.push_front(tw.x);
+            if ((int)hist.size() > kTwinMaxWarm) hist.pop_back();
+        }
         std::vector<double> dl; tw.backsub(dl);
         const double nrm = (py ? lr : 1.0) * tw.update(dl);
         if (seconds_solve) *seconds_solve += now() - t1;

@@ -235,13 +235,28 @@ template <typename T> struct Engine : IEngine {
     H* A_last = nullptr;
     T *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr;
     double ms_amg_symbolic = 0;
-    T *omega_dev = nullptr, *one_dev = nullptr, *gscale_dev = nullptr, *xprev = nullptr, *xprev2 = nullptr, *pw_a = nullptr, *pw_b = nullptr, *rho_part = nullptr;
+    T *omega_dev = nullptr, *one_dev = nullptr, *gscale_dev = nullptr, *pw_a = nullptr, *pw_b = nullptr, *rho_part = nullptr;
     T* h_rho = nullptr;                 // pinned
     std::vector<double> omega_host;    // smoother damping per level (diagnostics)
     int lin_count = 0;
     int hier_age = -1, hier_max_age = kHierMaxAge, hier_slack = kHierSlack, iters_fresh = 0, iters_last = 0;   // -1: no valid hierarchy
-    bool have_prev = false;            // xprev holds the pose delta of the previous solve (warm start)
-    int n_prev = 0;                    // how many consecutive deltas are held (xprev, xprev2)
+    T* hist[kMaxWarm] = {};            // pose deltas of the last solves, newest first (warm start)
+    bool have_prev = false;            // hist[0] holds the pose delta of the previous solve
+    int n_prev = 0;                    // how many consecutive deltas are held
+    int n_tested = 0;                  // orders 1..n_tested of the warm start's extrapolation have an error in warm_err (k_save_x)
+    T* warm_err = nullptr;             // [kMaxWarm][nbC]
+    int* warm_order_dev = nullptr;     // the order the last warm start took (diagnostics)
+    // Coefficients of every extrapolation order (k_pack_x): row m-1 = (-1)^j C(m, j+1) a^(j+1), a = 1 - step.
+    void warm_coefficients(WarmTerms<T>& w) const {
+        const double a = 1.0 - step_scale();
+        for (int m = 1; m <= kMaxWarm; ++m) {
+            double binom = 1, apow = 1;
+            for (int j = 1; j <= kMaxWarm; ++j) {
+                if (j <= m) { binom = binom * (m - j + 1) / j; apow *= a; w.c[m - 1][j - 1] = (T)((j & 1 ? 1.0 : -1.0) * binom * apow); }
+                else w.c[m - 1][j - 1] = T(0);
+            }
+        }
+    }
     int coarse_sweeps = kCoarseSweeps;
     std::vector<int> sweeps_list;      // research: sweeps per side on levels 1, 2, ... (TSGO_SWEEPS_LIST="2,2,1"; the last entry repeats)
     int nu_at(size_t l) const {
@@ -691,7 +706,7 @@ template <typename T> struct Engine : IEngine {
 
     // solver state a fresh engine starts from: whatever was learnt on the previous graph must not leak into this one
     int reset_solver_state() {
-        have_prev = false; n_prev = 0; predicted_cg = 0; lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
+        have_prev = false; n_prev = 0; n_tested = 0; predicted_cg = 0; lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
         const T one = 1;
         { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
         { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
@@ -800,8 +815,9 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&npart, (size_t)nbC + std::max(nbL, 1))) return rc;
         if (int rc = dalloc(&one_dev, 1)) return rc;
         if (int rc = dalloc(&gscale_dev, 1)) return rc;
-        if (int rc = dalloc(&xprev, (size_t)P * 3)) return rc;
-        if (int rc = dalloc(&xprev2, (size_t)P * 3)) return rc;
+        for (int j = 0; j < kMaxWarm; ++j) if (int rc = dalloc(&hist[j], (size_t)P * 3)) return rc;
+        if (int rc = dalloc(&warm_err, (size_t)kMaxWarm * nbC)) return rc;
+        if (int rc = dalloc(&warm_order_dev, 1)) return rc;
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
         HIP_OK(hipStreamSynchronize(stream));
@@ -1222,14 +1238,18 @@ template <typename T> struct Engine : IEngine {
     // is still to go at the next linearisation.  x0 = that remainder, r = b~ - S x0 (one extra product), and the stopping
     // rule keeps measuring against the right-hand side: gamma0 is scaled by (b^T D^-1 b) / (r0^T D^-1 r0).
     int launch_warm() {
-        // x0 = the un-taken remainder of the previous step, (1 - step) d1 — plus, from the third solve on, the same remainder of
-        // what the last step itself added over ITS prediction: with c1 = d1 - (1 - step) d2 the damped iteration repeats
-        // d_next ~ (1 - step) (d1 + c1).  Saves another 1-2 iterations per solve (profiles/r02f_warm_start_extrapolation.txt).
-        const T a = (T)(1.0 - step_scale());
-        if (n_prev >= 2 && cfg.warm_start >= 2)
-            hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, (T)(2 * a), (const T*)xprev2, (T)(-a * a));
-        else
-            hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, (T*)nullptr, (const T*)xprev, a, (const T*)nullptr, T(0));
+        // x0 = the un-taken remainder of the previous step, (1 - step) d1, at order 1; higher orders continue the trend of the last
+        // deltas as well (order 2: (1 - step) (d1 + c1) with c1 = d1 - (1 - step) d2, what the last step added over ITS prediction).
+        // cfg.warm_start caps the order; below the cap the kernel takes the order that would have predicted the last delta best
+        // (k_save_x measured every order then): high orders win once the iteration is smooth (50 iterations at 100 k poses:
+        // 849 PCG iterations at order 2, 724 at order 6) and lose while Huber weights still switch (profiles/r03w_warm_start_order.txt).
+        WarmTerms<T> w{};
+        warm_coefficients(w);
+        for (int j = 0; j < kMaxWarm; ++j) w.v[j] = hist[j];
+        w.n_max = std::max(1, std::min({n_prev, (int)cfg.warm_start, kMaxWarm}));
+        w.n_tested = std::min(n_tested, w.n_max);
+        w.errpart = warm_err; w.nb_err = nbC;
+        hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, x, zc, w, warm_order_dev);
         if (int rc = launch_matvec(0)) return rc;
         hipLaunchKernelGGL((k_warm_residual<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const T*)sbuf, (const T*)minv, r, zc, (const T*)(amg_on ? omega_dev : one_dev), npart, amg_on && low_cycle ? zc32 : (float*)nullptr);
         hipLaunchKernelGGL((k_warm_scale<T>), dim3(1), dim3(kBlock), 0, stream, nbC, (const T*)gpart[0], (const T*)npart, amg_on ? (T*)nullptr : gpart[0], gscale_dev,
@@ -1237,8 +1257,19 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
     int do_solve(int* iters, int* fail) {
-        if (cfg.warm_start && have_prev) { if (int rc = launch_warm()) return rc; }
+        const bool warmed = cfg.warm_start && have_prev && step_scale() < 1.0;      // a full step (rules = 1, lr = 1) leaves no remainder to start from
+        if (warmed) { if (int rc = launch_warm()) return rc; }
         if (int rc = do_solve_once(iters, fail)) return rc;
+        static const bool warm_trace = getenv("TSGO_SOLVE_TIMING") != nullptr;
+        if (warm_trace && warmed) {
+            int order = 0; T gs = 0; std::vector<T> e((size_t)kMaxWarm * nbC);
+            if (int rc = copy_sync(&order, warm_order_dev, sizeof(int), hipMemcpyDeviceToHost)) return rc;
+            if (int rc = copy_sync(&gs, gscale_dev, sizeof(T), hipMemcpyDeviceToHost)) return rc;
+            if (int rc = copy_sync(e.data(), warm_err, e.size() * sizeof(T), hipMemcpyDeviceToHost)) return rc;
+            std::fprintf(stderr, "[tsgo] warm start: order %d of %d tested, b'D^-1 b / r0'D^-1 r0 = %.3e, %d PCG iterations; prediction errors of the last delta:", order, n_tested, (double)gs, *iters);
+            for (int m = 0; m < n_tested; ++m) { double s = 0; for (int k = 0; k < nbC; ++k) s += (double)e[(size_t)m * nbC + k]; std::fprintf(stderr, " %.3e", s); }
+            std::fprintf(stderr, "\n");
+        }
         if (*fail == 3 && amg_on) *fail = 1;          // stagnation under the multigrid cycle
         if (amg_on && cy16 && (*fail != 0 || *iters > kPackedCycleMaxIters)) {
             // Packed half floats round every block of the cycle's operators to 11 bits.  A coarse operator of a nearly singular
@@ -1326,9 +1357,18 @@ template <typename T> struct Engine : IEngine {
     // rank: pose vectors are replicated) and THIS rank's ||delta_l||^2 (landmark deltas are shard-local).
     int do_backsub_update(T step, double* np2_out, double* nl2_local_out) {
         const int P = pr.P;
-        if (step != T(0)) std::swap(xprev, xprev2);      // the delta before this one (a probe, step 0, leaves the history alone)
-        hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, zc, step != T(0) ? xprev : (T*)nullptr, (const T*)nullptr, T(0), (const T*)nullptr, T(0));
-        if (step != T(0)) { have_prev = true; n_prev = std::min(n_prev + 1, 2); } else { have_prev = false; n_prev = 0; }   // a probe leaves nothing to carry over
+        if (step != T(0)) {
+            std::rotate(hist, hist + kMaxWarm - 1, hist + kMaxWarm);      // the oldest buffer takes this delta; hist[1..] are the deltas before it
+            WarmTerms<T> w{};
+            warm_coefficients(w);
+            for (int j = 0; j + 1 < kMaxWarm; ++j) w.v[j] = hist[j + 1];
+            w.n_max = std::min({n_prev, (int)cfg.warm_start, kMaxWarm - 1});      // orders that can be tested on this delta
+            hipLaunchKernelGGL((k_save_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, (const T*)x, zc, hist[0], w, warm_err);
+            n_tested = w.n_max; have_prev = true; n_prev = std::min(n_prev + 1, kMaxWarm);
+        } else {      // a probe (step 0) leaves nothing to carry over
+            hipLaunchKernelGGL((k_pack_x<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, zc, WarmTerms<T>{}, (int*)nullptr);
+            have_prev = false; n_prev = 0; n_tested = 0;
+        }
         if (tl.n_slices > 0) LAUNCH_GM(pr.by_lm.G, k_schur_lm, 1, nbL, stream, tl, zc, lmrec, (const T*)ninv, tvec, st[0], step, dl, npart + nbC);
         hipLaunchKernelGGL((k_pose_update<T>), dim3(nbC), dim3(kBlock), 0, stream, P, x, ps, theta, step, npart);
         const int nl = tl.n_slices > 0 ? nbL : 0;

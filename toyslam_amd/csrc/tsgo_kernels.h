@@ -568,24 +568,81 @@ __global__ __launch_bounds__(kBlock) void k_cg_update(int P, const T* __restrict
     if (writer) { n.gamma_old = gamma; n.alpha_old = alpha; n.iters = s.iters + 1; *st_out = n; }
 }
 
-// x -> zc[.][0..2] (the landmark pass reads its vector from zc)
-// scale = 0: plain copy of x into zc (and into xsave when given).  scale != 0 (warm start): x = scale * xprev + scale2 * xprev2
-// first (xprev2 may be null: first term only).
+// Warm start, first half.  d_k / a^k (a = 1 - step: what a damped step leaves of its delta) is smooth in k, so the next delta is
+// predicted by continuing the polynomial of degree m - 1 through the last m deltas: x0 = sum_j c[m-1][j] v[j],
+// c[m-1][j] = (-1)^j C(m, j+1) a^(j+1).  Which order m: the one that would have predicted the LAST delta best from the
+// deltas before it — k_save_x leaves ||d - prediction_m||^2 for every order it could test in errpart[m-1][block].
+constexpr int kMaxWarm = 6;      // deltas of earlier Gauss-Newton iterations the warm start can combine
+constexpr int kWarmMargin = 4;   // a higher order is taken when its squared prediction error is this many times smaller: its coefficients
+                                 // (order 4 at step 0.2: 3.2, -3.8, 2.0, -0.4) amplify whatever in the deltas is not a smooth trend
+template <typename T> struct WarmTerms {
+    const T* v[kMaxWarm];          // deltas, newest first
+    T c[kMaxWarm][kMaxWarm];       // row m-1: the coefficients of order m
+    int n_max;                     // highest order allowed (0: no warm start — plain copy)
+    int n_tested;                  // orders 1..n_tested have an error in errpart
+    const T* errpart; int nb_err;  // [kMaxWarm][nb_err]
+};
+
+// x -> zc[.][0..2] (the landmark pass reads its vector from zc).  w.n_max = 0: plain copy of x into zc.  Otherwise x = the
+// prediction of the order with the smallest tested error (order 1 when nothing has been tested yet) first.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_pack_x(int P, T* __restrict__ x, T* __restrict__ zc, T* __restrict__ xsave,
-                                                   const T* __restrict__ xprev, T scale, const T* __restrict__ xprev2, T scale2) {
+__global__ __launch_bounds__(kBlock) void k_pack_x(int P, T* __restrict__ x, T* __restrict__ zc, const WarmTerms<T> w, int* __restrict__ order_out) {
+    __shared__ T red[kWavesPerBlock];
     const int i = blockIdx.x * kBlock + threadIdx.x;
+    int m = w.n_max > 0 ? 1 : 0;
+    if (w.n_max > 0 && w.n_tested > 0) {          // every workgroup sums the same partials in the same order: one choice
+        T best = block_sum_array<T>(w.errpart, w.nb_err, red);
+        for (int j = 1; j < w.n_tested && j < w.n_max; ++j) {
+            const T e = block_sum_array<T>(w.errpart + (size_t)j * w.nb_err, w.nb_err, red);
+            if (e * kWarmMargin < best) { best = e; m = j + 1; }
+        }
+    }
+    if (order_out && blockIdx.x == 0 && threadIdx.x == 0) *order_out = m;
     if (i >= P) return;
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
         T v = x[(size_t)i * 3 + k];
-        if (scale != T(0)) {
-            v = scale * xprev[(size_t)i * 3 + k];
-            if (xprev2) v += scale2 * xprev2[(size_t)i * 3 + k];
+        if (m > 0) {
+            v = w.c[m - 1][0] * w.v[0][(size_t)i * 3 + k];
+            for (int j = 1; j < m; ++j) v += w.c[m - 1][j] * w.v[j][(size_t)i * 3 + k];
             x[(size_t)i * 3 + k] = v;
         }
         zc[(size_t)i * kPoseRec + k] = v;
-        if (xsave) xsave[(size_t)i * 3 + k] = v;
+    }
+}
+
+// The solved delta x -> zc[.][0..2] and -> xsave (the newest entry of the warm start's history), and what every order would
+// have made of predicting it from the deltas before it (w.v, newest first; orders 1..w.n_max): errpart[m-1][block].
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_save_x(int P, const T* __restrict__ x, T* __restrict__ zc, T* __restrict__ xsave, const WarmTerms<T> w, T* __restrict__ errpart) {
+    __shared__ T red[kWavesPerBlock];
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    T err[kMaxWarm];
+#pragma unroll
+    for (int m = 0; m < kMaxWarm; ++m) err[m] = 0;
+    if (i < P) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+            const T v = x[(size_t)i * 3 + k];
+            zc[(size_t)i * kPoseRec + k] = v;
+            xsave[(size_t)i * 3 + k] = v;
+            T u[kMaxWarm];
+#pragma unroll
+            for (int j = 0; j < kMaxWarm; ++j) u[j] = j < w.n_max ? w.v[j][(size_t)i * 3 + k] : T(0);
+#pragma unroll
+            for (int m = 0; m < kMaxWarm; ++m) {
+                if (m < w.n_max) {
+                    T p = 0;
+#pragma unroll
+                    for (int j = 0; j <= m; ++j) p += w.c[m][j] * u[j];
+                    err[m] += (v - p) * (v - p);
+                }
+            }
+        }
+    }
+    for (int m = 0; m < w.n_max; ++m) {
+        const T total = block_sum<T>(err[m], red);
+        if (threadIdx.x == 0) errpart[(size_t)m * gridDim.x + blockIdx.x] = total;
     }
 }
 

@@ -93,6 +93,15 @@ typedef struct tsgo_config {
                                 bytes).  A preconditioner tolerates the 11-bit blocks; PCG's own operator and every vector stay in
                                 `precision`.  Same answers, the same or one more PCG iteration per solve, fewer bytes per iteration.  A structure whose solves
                                 take more than 64 iterations (nearly singular systems: long odometry-only chains) is moved to 32 by the engine. */
+    int32_t warm_requests;   /* 0 (default): every tsgo_set_graph starts the solver from nothing, so a handle's results are bit-identical to a
+                                fresh handle's.  1: the warm start's history (the pose deltas of the last Gauss-Newton iterations) survives
+                                tsgo_set_graph — a SLAM front-end resends the graph with the estimates it was returned, plus what it has seen
+                                since (python/slam_main.py:215-238), so the next request continues the damped iteration where the last one
+                                stopped.  Same structure: the history stays; a new (grown) structure: it is carried over by vertex id, poses the
+                                old graph did not hold start from zero.  A history that does not fit the new request (the first warm start
+                                leaves a larger residual than a cold start would) is dropped at that solve.  Same answer to pcg_rel_tol.
+                                ("warm-starting PCG across requests"; the reference re-creates everything per message,
+                                remote/app/ConnectionHandler.h:18-21.)  What graph_optimizer runs by default. */
 } tsgo_config;
 
 enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_CONVERGED = 3, TSGO_STOP_SOLVER = 4 };
@@ -117,6 +126,10 @@ typedef struct tsgo_stats {
     int32_t trace_len;                   /* entries of chi2[] / pcg_iters[] that are valid: min(iterations_run, TSGO_MAX_TRACE) */
     double chi2_last;                    /* chi^2 of the LAST linearisation (`Summary() error`, OptimizerCpu.h:182), also when the
                                             run is longer than the trace */
+    int32_t history_carried;             /* tsgo_config.warm_requests: 1 when this run started from the solver history of the handle's previous
+                                            request (kept in place or carried over by vertex id), 2 when it did and the first solve dropped it
+                                            (it did not fit the new estimates), 0 otherwise */
+    int32_t pad_;
 } tsgo_stats;
 
 /* Fills cfg with defaults. */

@@ -8,7 +8,8 @@ import pytest
 from oracle import oracle
 from tests import edge_cases, util
 from toyslam_amd import synth
-from toyslam_amd.optimizer import HipOptimizer
+from toyslam_amd.graph import GraphArrays
+from toyslam_amd.optimizer import HipOptimizer, free_local_group, local_group
 
 pytestmark = pytest.mark.gpu
 
@@ -202,6 +203,101 @@ def test_collective_path_at_config_2_size_keeps_multigrid_iteration_counts():
     ref = oracle.sparse_optimize(util.to_oracle(g), 6, pcg_tol=1e-12, precond="jacobi")
     np.testing.assert_allclose(rb["chi2"], ref["chi2"], rtol=1e-9)
     assert util.max_vertex_diff(vb, ref["v_pos"], g.v_type) < 1e-7
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_solver_history_survives_set_graph_when_asked_to(world):
+    """SURVEY 8f rank 2, "warm-starting PCG across requests" (tsgo_config.warm_requests; the reference re-creates everything per
+    message, remote/app/ConnectionHandler.h:18-21).  A front-end sends back the estimates it was returned: (a) the same structure —
+    the deltas of the last Gauss-Newton iterations stay in place; (b) the graph grown by 400 poses and what they see — carried
+    over by vertex id into the new pose numbering, new poses start from zero; (c) a request that does NOT continue the last one
+    (the same graph with estimates that are already converged: the history predicts steps that are not there): the first warm
+    start leaves a larger residual than a cold one and the history is dropped.  Every time: the
+    same chi^2 trajectory and vertices as a fresh handle to the PCG tolerance, in fewer PCG iterations where the history fits.
+    world = 2: two shards through the in-process group take every one of those decisions alike."""
+    import threading
+    big = synth.make(4400, 10, loop_closures=0, seed=21)
+    small = util.first_poses(big, 4000)
+    assert small.n_poses == 4000 and 0 < small.n_landmarks < big.n_landmarks and len(small.e_type) < len(big.e_type)
+
+    def returned(g, v):      # what comes back over the wire: f32
+        return GraphArrays(g.v_id, g.v_type, v.astype(np.float32).astype(np.float64), g.e_type, g.e_ids, g.e_meas, g.e_inf, g.fixed)
+
+    def run(warm, requests, iterations=6, world=world):
+        """`requests`: functions (previous (graph, vertices) or None) -> graph, sent one after the other to ONE handle per rank;
+        returns [(result of rank 0, vertices merged over the ranks, graph, results of all ranks)] per request"""
+        group = local_group(world) if world > 1 else None
+        hs = [HipOptimizer(pcg_rel_tol=1e-12, rank=k, world=world, warm_requests=warm) for k in range(world)]
+        res = []; prev = None
+        try:
+            if world > 1:
+                for o in hs:
+                    o.comm_init_local(group)
+            for make in requests:
+                g = make(prev)
+                outs = [None] * world; errs = []
+
+                def rank_main(rank, g=g, outs=outs, errs=errs):
+                    try:
+                        hs[rank].set_graph(g); r = hs[rank].optimize(iterations); outs[rank] = (r, hs[rank].vertices())
+                    except Exception as e:      # noqa: BLE001
+                        errs.append((rank, repr(e)))
+
+                th = [threading.Thread(target=rank_main, args=(k,), daemon=True) for k in range(world)]
+                for t in th:
+                    t.start()
+                for t in th:
+                    t.join(timeout=300)
+                assert not errs, errs
+                assert not any(t.is_alive() for t in th), "a rank is stuck in the in-process all-reduce (the ranks decided differently?)"
+                v = outs[0][1].copy()            # poses are replicated; a landmark comes from the shard that owns (and moved) it
+                for _, vr in outs[1:]:
+                    m = np.any(vr != g.v_pos, axis=1) & (g.v_type == 1)
+                    v[m] = vr[m]
+                res.append((outs[0][0], v, g, [o[0] for o in outs])); prev = (g, v)
+        finally:
+            for o in hs:
+                o.close()
+            if world > 1:
+                free_local_group(group)
+        return res
+
+    def grown_from(prev):
+        g, v = prev
+        at = {int(i): k for k, i in enumerate(g.v_id)}
+        vp = big.v_pos.copy()
+        for k, i in enumerate(big.v_id):
+            j = at.get(int(i))
+            if j is not None:
+                vp[k] = np.float32(v[j]).astype(np.float64)
+        return GraphArrays(big.v_id, big.v_type, vp, big.e_type, big.e_ids, big.e_meas, big.e_inf, big.fixed)
+
+    requests = [lambda prev: small,
+                lambda prev: returned(*prev),            # (a) same structure, the estimates that came back
+                grown_from,                              # (b) grown, old vertices as returned
+                lambda prev: settled]                    # (c) same structure as (b), estimates that have converged elsewhere: not a continuation
+    vs = run(False, [lambda prev: big], iterations=40, world=1)[0][1]
+    settled = GraphArrays(big.v_id, big.v_type, vs, big.e_type, big.e_ids, big.e_meas, big.e_inf, big.fixed)
+    warm = run(True, requests)
+    for r, _, _, ranks in warm:
+        for rr in ranks[1:]:
+            np.testing.assert_array_equal(rr["chi2"], r["chi2"]); np.testing.assert_array_equal(rr["cg_iters"], r["cg_iters"])
+            assert rr["history_carried"] == r["history_carried"]
+    assert [r["history_carried"] for r, _, _, _ in warm] == [0, 1, 1, 2], [r["history_carried"] for r, _, _, _ in warm]
+    assert warm[1][0]["structure_reused"] and not warm[2][0]["structure_reused"] and warm[3][0]["structure_reused"]
+    # a fresh single handle per request, on exactly the graphs the warm handles were given
+    for k, (r, v, g, _) in enumerate(warm):
+        rc, vc, _, _ = run(False, [lambda prev, g=g: g], world=1)[0]
+        assert rc["history_carried"] == 0
+        np.testing.assert_allclose(r["chi2"], rc["chi2"], rtol=1e-9)
+        assert util.max_vertex_diff(v, vc, g.v_type) < 1e-8
+        print("request %d (%d poses, %d shard(s)): PCG iterations per solve with the history %s, from nothing %s" % (k, g.n_poses, world, list(r["cg_iters"]), list(rc["cg_iters"])))
+        if k == 1:
+            assert r["cg_iters"][0] < rc["cg_iters"][0] and r["cg_iters"].sum() < rc["cg_iters"].sum()
+        if k == 2:
+            assert r["cg_iters"].sum() <= rc["cg_iters"].sum() + 3
+        if k in (0, 3):
+            assert abs(int(r["cg_iters"].sum()) - int(rc["cg_iters"].sum())) <= 3 + 3 * (world - 1)      # nothing carried / dropped at the first solve
 
 
 @pytest.mark.parametrize("precond,precision", [("amg", 64), ("jacobi", 64), ("amg", 32)])

@@ -55,3 +55,19 @@ def max_vertex_diff(v1, v2, v_type):
     d = np.abs(v1 - v2)
     d[:, 2] = np.where(v_type == 0, np.abs(angle_diff(v1[:, 2], v2[:, 2])), 0.0)
     return float(d.max())
+
+
+def first_poses(g, n_poses):
+    """The graph a SLAM front-end held when it had seen the first `n_poses` poses of g: those poses (ids 0..n_poses-1 in the
+    synthetic graphs), the landmarks they observe and the edges among them, with g's own vertex ids (python/slam_main.py:157-187
+    rebuilds and resends exactly such a growing graph)."""
+    pose = g.v_type == 0
+    keep_pose_id = set(int(i) for i in g.v_id[pose][:n_poses])
+    e1_in = np.isin(g.e_ids[:, 0], list(keep_pose_id))
+    lm_edge = (g.e_type == 1) & e1_in
+    keep_lm_id = np.unique(g.e_ids[lm_edge, 1])
+    keep_v = (pose & np.isin(g.v_id, list(keep_pose_id))) | ((g.v_type == 1) & np.isin(g.v_id, keep_lm_id))
+    kept_ids = g.v_id[keep_v]
+    keep_e = np.isin(g.e_ids[:, 0], kept_ids) & np.isin(g.e_ids[:, 1], kept_ids)
+    return GraphArrays(g.v_id[keep_v], g.v_type[keep_v], g.v_pos[keep_v], g.e_type[keep_e], g.e_ids[keep_e], g.e_meas[keep_e], g.e_inf[keep_e],
+                       g.fixed[np.isin(g.fixed, kept_ids)])

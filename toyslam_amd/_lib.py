@@ -12,7 +12,7 @@ class tsgo_config(C.Structure):
     _fields_ = [("device", C.c_int32), ("precision", C.c_int32), ("pcg_rel_tol", C.c_double),
                 ("pcg_max_iters", C.c_int32), ("lanes_per_pose", C.c_int32), ("lanes_per_lm", C.c_int32),
                 ("use_graphs", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("verbose", C.c_int32),
-                ("preconditioner", C.c_int32), ("xcd_map", C.c_int32), ("warm_start", C.c_int32), ("rules", C.c_int32), ("lr", C.c_double), ("odom_jacobian", C.c_int32), ("reuse_structure", C.c_int32), ("cycle_level0", C.c_int32), ("cycle_storage", C.c_int32)]
+                ("preconditioner", C.c_int32), ("xcd_map", C.c_int32), ("warm_start", C.c_int32), ("rules", C.c_int32), ("lr", C.c_double), ("odom_jacobian", C.c_int32), ("reuse_structure", C.c_int32), ("cycle_level0", C.c_int32), ("cycle_storage", C.c_int32), ("warm_requests", C.c_int32)]
 
 
 class tsgo_stats(C.Structure):
@@ -21,7 +21,7 @@ class tsgo_stats(C.Structure):
                 ("ms_total", C.c_double), ("ms_linearize", C.c_double), ("ms_solve", C.c_double),
                 ("ms_update", C.c_double), ("ms_setup", C.c_double), ("structure_reused", C.c_int32), ("cycle_storage_now", C.c_int32), ("lambda_last", C.c_double), ("n_pose", C.c_int64), ("n_lm", C.c_int64),
                 ("n_odom_edges", C.c_int64), ("n_lm_edges", C.c_int64), ("pcg_iters_total", C.c_int64),
-                ("pcg_fallbacks", C.c_int32), ("trace_len", C.c_int32), ("chi2_last", C.c_double)]
+                ("pcg_fallbacks", C.c_int32), ("trace_len", C.c_int32), ("chi2_last", C.c_double), ("history_carried", C.c_int32), ("pad_", C.c_int32)]
 
 
 class tsgo_cycle_level(C.Structure):

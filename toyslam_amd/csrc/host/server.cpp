@@ -1,10 +1,11 @@
 // server.cpp — `graph_optimizer`: drop-in for ToySlam's remote optimizer process.
 //
 //   graph_optimizer [HOST=127.0.0.1] [PORT=8888] [ITERATIONS=10] [PIPELINE=cpu] [SOLVER=eigen]
-//                   [PRECISION=64] [PCG_TOL=1e-10] [DEVICE=0] [ENGINES=2] [RULES=cpp] [ODOM_JACOBIAN=constant]
+//                   [PRECISION=64] [PCG_TOL=1e-10] [DEVICE=0] [ENGINES=2] [RULES=cpp] [ODOM_JACOBIAN=constant] [WARM_REQUESTS=1]
 //   RULES "python" or "python:LR": the loop of the reference's in-process Python optimizer instead (lambda * I damping, step LR,
 //   default 0.2 as slam_main.py passes); ODOM_JACOBIAN "analytic": the extension of tsgo_config.odom_jacobian.  Both default to
-//   what the reference's C++ server does.
+//   what the reference's C++ server does.  WARM_REQUESTS 1: tsgo_config.warm_requests (a connection's next request starts its PCG
+//   solves from the history of its last one; same answers to PCG_TOL), 0: every request starts from nothing.
 //
 // Positional arguments 1-5 are the reference's (remote/app/main.cpp:12-16, README.md:15-18).  The
 // reference maps PIPELINE "cpu" -> CPU optimizer and anything else -> GPU, SOLVER "eigen" -> Eigen and
@@ -243,6 +244,7 @@ int main(int argc, char* argv[]) {
         const int engines = argc < 10 ? 2 : std::max(1, std::stoi(argv[9]));
         const std::string rulesS = argc < 11 ? "cpp" : argv[10];
         const std::string odomS = argc < 12 ? "constant" : argv[11];
+        const int warm_requests = argc < 13 ? 1 : std::stoi(argv[12]);
         // the reference prints the enums after forcing them to what the build supports (main.cpp:21-34):
         // 0 = EIGEN, 1 = CUDA; here both are always the accelerator pipeline.
         std::cout << "iters: " << iters << ", optimizerType: 1, solverType: 1" << std::endl;
@@ -259,6 +261,7 @@ int main(int argc, char* argv[]) {
             std::cout << "rules: python/optimizer/graph_optimizer.py (lambda * I, lr " << cfg.lr << ")\n";
         }
         if (odomS == "analytic") { cfg.odom_jacobian = 1; std::cout << "ODOM Jacobians: analytic (extension)\n"; }
+        cfg.warm_requests = warm_requests ? 1 : 0;      // a connection's next request continues from the last one's solver history (tsgo.h)
         Server srv; srv.iterations = iters; srv.cfg = cfg; srv.max_engines = engines;
         if (const char* e = getenv("TSGO_MAX_MESSAGE_MB")) srv.max_message_bytes = (size_t)std::max(1, atoi(e)) << 20;
         {   // fail at start-up, like the reference, when the pipeline cannot be created at all

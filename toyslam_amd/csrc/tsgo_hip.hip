@@ -18,6 +18,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/tsgo.h"
@@ -279,7 +280,7 @@ template <typename T> struct Engine : IEngine {
         if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
     }
 
-    ~Engine() override { release(); for (Slab& sl : slabs) (void)hipFree(sl.base); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); if (stream2) (void)hipStreamDestroy(stream2); for (auto& e : ev) if (e) (void)hipEventDestroy(e); for (auto& m : prof) (void)hipEventDestroy(m.e); }
+    ~Engine() override { release(); for (Slab& sl : slabs) (void)hipFree(sl.base); if (carry_dev) (void)hipFree(carry_dev); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); if (stream2) (void)hipStreamDestroy(stream2); for (auto& e : ev) if (e) (void)hipEventDestroy(e); for (auto& m : prof) (void)hipEventDestroy(m.e); }
 
     void release() {
         if (amg_builder.joinable()) amg_builder.join();
@@ -706,7 +707,7 @@ template <typename T> struct Engine : IEngine {
 
     // solver state a fresh engine starts from: whatever was learnt on the previous graph must not leak into this one
     int reset_solver_state() {
-        have_prev = false; n_prev = 0; n_tested = 0; predicted_cg = 0; lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
+        have_prev = false; n_prev = 0; n_tested = 0; carried = false; predicted_cg = 0; lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
         const T one = 1;
         { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
         { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
@@ -719,6 +720,65 @@ template <typename T> struct Engine : IEngine {
     }
 
     // Same structure as the graph the tables were built for: refill values, keep everything else.
+    // ---- solver history across requests (tsgo_config.warm_requests) --------------------------------------------------------------
+    // The deltas of the last Gauss-Newton iterations outlive tsgo_set_graph: in place when the structure is the same, carried over by
+    // vertex id when it is not (the slabs are reused by the new tables, so the vectors are parked in an allocation of their own).
+    struct Carry { int n = 0, n_tested = 0, P = 0; std::vector<uint32_t> pose_id; double err[kMaxWarm] = {}; } carry;
+    T* carry_dev = nullptr; size_t carry_cap = 0;
+    bool carried = false;        // the history came from the previous request: the first warm start made from it is checked (do_solve)
+    int n_carried = 0, n_carry_dropped = 0;
+    int carry_out() {
+        carry.n = 0;
+        if (!cfg.warm_requests || !have_graph_data || !have_prev || n_prev <= 0 || pr.P <= 0) return 0;
+        const size_t n = (size_t)pr.P * 3;
+        if ((size_t)n_prev * n > carry_cap) {
+            if (carry_dev) { (void)hipFree(carry_dev); carry_dev = nullptr; carry_cap = 0; }
+            HIP_OK(hipMalloc((void**)&carry_dev, (size_t)kMaxWarm * n * sizeof(T)));
+            carry_cap = (size_t)kMaxWarm * n;
+        }
+        for (int j = 0; j < n_prev; ++j) HIP_OK(hipMemcpyAsync(carry_dev + (size_t)j * n, hist[j], n * sizeof(T), hipMemcpyDeviceToDevice, stream));
+        std::vector<T> e((size_t)kMaxWarm * nbC);
+        if (int rc = copy_sync(e.data(), warm_err, e.size() * sizeof(T), hipMemcpyDeviceToHost)) return rc;
+        for (int m = 0; m < kMaxWarm; ++m) { double s = 0; for (int k = 0; k < nbC; ++k) s += (double)e[(size_t)m * nbC + k]; carry.err[m] = s; }
+        carry.pose_id.resize((size_t)pr.P);
+        for (int i = 0; i < pr.P; ++i) carry.pose_id[(size_t)i] = structure.v_id[(size_t)pr.pose_vertex[(size_t)i]];
+        HIP_OK(hipStreamSynchronize(stream));
+        carry.P = pr.P; carry.n = n_prev; carry.n_tested = n_tested;
+        return 0;
+    }
+    // after the new tables exist (hist, warm_err allocated; solver state reset): the parked deltas into the new pose numbering
+    int carry_in(const tsgo_graph& g) {
+        if (carry.n <= 0) return 0;
+        const int n_old = carry.n; carry.n = 0;
+        uint32_t max_id = 0;
+        for (uint32_t id : carry.pose_id) max_id = std::max(max_id, id);
+        const bool flat = (uint64_t)max_id < 8ull * (uint64_t)carry.P + 1024;
+        std::vector<int> table(flat ? (size_t)max_id + 1 : 0, -1);
+        std::unordered_map<uint32_t, int> by_id;
+        if (flat) for (int i = 0; i < carry.P; ++i) table[carry.pose_id[(size_t)i]] = i;
+        else { by_id.reserve((size_t)carry.P * 2); for (int i = 0; i < carry.P; ++i) by_id.emplace(carry.pose_id[(size_t)i], i); }
+        std::vector<int> src((size_t)pr.P);
+        int found = 0;
+        for (int i = 0; i < pr.P; ++i) {
+            const uint32_t id = g.v_id[(size_t)pr.pose_vertex[(size_t)i]];
+            int j = -1;
+            if (flat) { if (id <= max_id) j = table[id]; } else { auto it = by_id.find(id); if (it != by_id.end()) j = it->second; }
+            src[(size_t)i] = j; found += j >= 0;
+        }
+        if (2 * (int64_t)found < (int64_t)std::min(pr.P, carry.P)) return 0;      // another graph altogether: nothing to continue
+        int* src_dev = nullptr;
+        if (int rc = upload_i32(&src_dev, src)) return rc;
+        const size_t n = (size_t)carry.P * 3;
+        for (int j = 0; j < n_old; ++j)
+            hipLaunchKernelGGL((k_gather_hist<T>), dim3(nbC), dim3(kBlock), 0, stream, pr.P, (const int*)src_dev, (const T*)(carry_dev + (size_t)j * n), hist[j]);
+        std::vector<T> e((size_t)kMaxWarm * nbC, T(0));
+        for (int m = 0; m < kMaxWarm; ++m) e[(size_t)m * nbC] = (T)carry.err[m];
+        if (int rc = copy_sync(warm_err, e.data(), e.size() * sizeof(T), hipMemcpyHostToDevice)) return rc;
+        HIP_OK(hipStreamSynchronize(stream));
+        have_prev = true; n_prev = n_old; n_tested = carry.n_tested; carried = true; ++n_carried;
+        return 0;
+    }
+
     int refill(const tsgo_graph& g) {
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = refill_values(g);
@@ -748,7 +808,10 @@ template <typename T> struct Engine : IEngine {
                 if (!rel.empty()) { if (int rc_ = copy_sync(lv[l].rel, stage, rel.size() * sizeof(T), hipMemcpyHostToDevice)) return rc_; }
             }
         }
+        const bool keep = cfg.warm_requests && have_prev && n_prev > 0;      // same structure, same numbering: the history stays where it is
+        const int keep_prev = n_prev, keep_tested = n_tested;
         if (int rc = reset_solver_state()) return rc;
+        if (keep) { have_prev = true; n_prev = keep_prev; n_tested = keep_tested; carried = true; ++n_carried; }
         HIP_OK(hipStreamSynchronize(stream));
         return 0;
     }
@@ -759,6 +822,7 @@ template <typename T> struct Engine : IEngine {
         if (g.n_vertices < 0 || g.n_edges < 0 || g.n_fixed < 0) return set_error(-2, "tsgo_set_graph: negative count");
         last_set_reused = have_graph_data && cfg.reuse_structure && structure.same_as(g);
         if (last_set_reused) return refill(g);
+        if (int rc = carry_out()) return rc;
         release();
         BuildOptions bo; bo.rank = cfg.rank; bo.world = cfg.world; bo.lanes_per_pose = cfg.lanes_per_pose; bo.lanes_per_lm = cfg.lanes_per_lm;
         bo.fill_planes = false;
@@ -824,6 +888,7 @@ template <typename T> struct Engine : IEngine {
         lap("state + slot tables to the device");
         if (amg_on) { if (int rc = upload_amg()) return rc; }
         if (int rc = reset_solver_state()) return rc;
+        if (int rc = carry_in(g)) return rc;
         HIP_OK(hipStreamSynchronize(stream));
         if (say) std::fprintf(stderr, "[tsgo] set_graph:   of which multigrid patterns on the host %8.1f ms (its pair-list products on the device: %.1f ms of that)\n", ms_amg_symbolic, ms_device_products);
         if (say) for (size_t l = 0; l < lv.size(); ++l)
@@ -1259,6 +1324,15 @@ template <typename T> struct Engine : IEngine {
     int do_solve(int* iters, int* fail) {
         const bool warmed = cfg.warm_start && have_prev && step_scale() < 1.0;      // a full step (rules = 1, lr = 1) leaves no remainder to start from
         if (warmed) { if (int rc = launch_warm()) return rc; }
+        if (warmed && carried) {
+            // The history is the previous REQUEST's: it continues this one only if the client sent back the estimates it was
+            // returned.  k_warm_scale leaves b'D^-1 b / r0'D^-1 r0, or 1 when the start is no better than zero: then the history
+            // is dropped and the solve starts cold (every shard reads the same all-reduced numbers and decides alike).
+            T gs = 0;
+            if (int rc = copy_sync(&gs, gscale_dev, sizeof(T), hipMemcpyDeviceToHost)) return rc;
+            if (!(gs > T(1))) { launch_finalize(); have_prev = false; n_prev = 0; n_tested = 0; ++n_carry_dropped; }
+        }
+        carried = false;
         if (int rc = do_solve_once(iters, fail)) return rc;
         static const bool warm_trace = getenv("TSGO_SOLVE_TIMING") != nullptr;
         if (warm_trace && warmed) {
@@ -1408,7 +1482,8 @@ template <typename T> struct Engine : IEngine {
         double prevErr = -1; int penalty = 0;
         bool nl2_whole = true;        // sharded: last_delta_norm holds every rank's landmark part (see landmark_norm_allreduce)
         double np2_last = 0, nl2_last = 0;
-        const int fallbacks0 = n_fallbacks;
+        const int fallbacks0 = n_fallbacks, dropped0 = n_carry_dropped;
+        const bool started_carried = carried;
         s.stop_reason = TSGO_STOP_CAP;
         const auto wall0 = std::chrono::steady_clock::now();
         // rules = 1 (graph_optimizer.py:24-31): lambda starts at 1e-3 on every call
@@ -1471,6 +1546,7 @@ template <typename T> struct Engine : IEngine {
             s.last_delta_norm = (py_rules() ? step_scale() : 1.0) * std::sqrt(np2_last + nl2_last);
         }
         s.pcg_fallbacks = n_fallbacks - fallbacks0;
+        s.history_carried = started_carried ? (n_carry_dropped > dropped0 ? 2 : 1) : 0;
         s.cycle_storage_now = amg_on ? (cy16 ? 16 : 32) : 0;
         s.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         if (out) *out = s;

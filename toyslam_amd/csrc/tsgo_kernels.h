@@ -646,6 +646,17 @@ __global__ __launch_bounds__(kBlock) void k_save_x(int P, const T* __restrict__ 
     }
 }
 
+// History across requests (tsgo_config.warm_requests): a delta of the previous graph, in ITS pose numbering, into this graph's —
+// src[i] = the old index of pose i, or -1 for a pose the old graph did not hold.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_gather_hist(int P, const int* __restrict__ src, const T* __restrict__ old, T* __restrict__ out) {
+    const int i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= P) return;
+    const int j = src[i];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) out[(size_t)i * 3 + k] = j >= 0 ? old[(size_t)j * 3 + k] : T(0);
+}
+
 // Warm start, second half: r = b~ - S x0 (S x0 in sx), zc = omega Minv r, partials of r^T Minv r.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_warm_residual(int P, const T* __restrict__ sx, const T* __restrict__ minv, T* __restrict__ r,

@@ -17,7 +17,7 @@ STOP = {0: "cap", 1: "worse", 2: "plateau", 3: "converged", 4: "solver_failed"}
 class HipOptimizer:
     def __init__(self, device=0, precision=64, pcg_rel_tol=1e-10, pcg_max_iters=20000, lanes_per_pose=0,
                  lanes_per_lm=0, use_graphs=True, rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None,
-                 reuse_structure=None, rules="cpp", lr=0.2, odom_jacobian="constant", cycle_level0="implicit", cycle_storage=16):
+                 reuse_structure=None, rules="cpp", lr=0.2, odom_jacobian="constant", cycle_level0="implicit", cycle_storage=16, warm_requests=False):
         self.lib = _lib.hip_lib()
         cfg = _lib.tsgo_config()
         self.lib.tsgo_default_config(C.byref(cfg))
@@ -35,6 +35,7 @@ class HipOptimizer:
         cfg.odom_jacobian = {"constant": 0, "analytic": 1}[odom_jacobian]
         cfg.cycle_level0 = {"implicit": 0, "explicit": 1}[cycle_level0]
         cfg.cycle_storage = {16: 16, 32: 32}[cycle_storage]
+        cfg.warm_requests = 1 if warm_requests else 0
         self.cfg = cfg
         self.h = C.c_void_p()
         _lib.check(self.lib, self.lib.tsgo_create(C.byref(cfg), C.byref(self.h)), "tsgo_create")
@@ -66,7 +67,7 @@ class HipOptimizer:
                     cg_iters=np.array(st.pcg_iters[:n]), delta_norm=st.last_delta_norm, ms_total=st.ms_total,
                     ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup, structure_reused=bool(st.structure_reused), lambda_last=st.lambda_last,
                     n_pose=st.n_pose, n_lm=st.n_lm, n_odom_edges=st.n_odom_edges, n_lm_edges=st.n_lm_edges,
-                    cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks, cycle_storage_now=st.cycle_storage_now)
+                    cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks, cycle_storage_now=st.cycle_storage_now, history_carried=st.history_carried)
 
     def vertices(self):
         out = np.zeros((self.n_vertices, 3)) if self._v_in is None else np.ascontiguousarray(self._v_in.copy())

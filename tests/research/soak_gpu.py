@@ -1,7 +1,9 @@
 """Research soak (GPU): random mid-size graphs, 12 GN iterations under the reference's stop rules, HIP path against
 the CPU twin (tight tolerances on both).  Exercises warm start, lagged hierarchy, matched aggregates on many shapes;
 round 2: every 4th graph with the analytic ODOM Jacobians, every 5th under the Python optimizer's rules (lambda * I, random
-lr), every 3rd sent again to the same handle (structure reuse: bit-identical answer)."""
+lr), every 3rd sent again to the same handle (structure reuse: bit-identical answer); round 3: every 3rd (+1) goes to a handle with
+tsgo_config.warm_requests and comes back with the returned estimates (f32, as over the wire): that second request, started from the
+first one's solver history — kept for this structure, or carried over from whatever graph the handle held before — against the twin."""
 import sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -52,6 +54,29 @@ while time.time() < t_end:
             o.set_graph(g); r2 = o.optimize(12)
             if not (r2["structure_reused"] and np.array_equal(r2["chi2"], r["chi2"]) and np.array_equal(r2["cg_iters"], r["cg_iters"])):
                 print("trial %d: the refilled handle did not reproduce the first run" % trial); sys.exit(1)
+        if trial % 3 == 1:
+            kw = key + ("warm",)
+            ow = handles.get(kw)
+            if ow is None:
+                ow = handles[kw] = HipOptimizer(pcg_rel_tol=1e-11, odom_jacobian=oj, rules=rules, lr=lr, warm_requests=True)
+            ow.set_graph(g); rw0 = ow.optimize(12); vw0 = ow.vertices()
+            g2 = GraphArrays(g.v_id, g.v_type, vw0.astype(np.float32).astype(np.float64), g.e_type, g.e_ids, g.e_meas, g.e_inf, g.fixed)
+            ow.set_graph(g2); rw = ow.optimize(12); vw = ow.vertices()
+            oracle.set_odom_jacobian(oj)
+            try:
+                refw = oracle.sparse_optimize(util.to_oracle(g2), 12, pcg_tol=1e-12, precond="amg", rules=rules, lr=lr)
+            finally:
+                oracle.set_odom_jacobian("constant")
+            dw = util.max_vertex_diff(vw, refw["v_pos"], g.v_type)
+            barw = 1e-6 * max(1.0, rw["delta_norm"] / 1e4) * (max(1.0, float(np.abs(refw["v_pos"]).max()) / 100.0) if oj == "analytic" else 1.0)
+            divw = refw["stop"] == "worse" or refw["chi2"][-1] > refw["chi2"][0]
+            beamw = shape.startswith("pose graph") and oj == "analytic"
+            okw = rw["iters"] == refw["iters"] and rw["stop"] == refw["stop"] and np.allclose(rw["chi2"], refw["chi2"], rtol=1e-6 if (divw or beamw) else 1e-8) \
+                and (divw or dw < (1e-4 if beamw else barw))      # a diverging run (chi^2 rising: pose graphs under the constant Jacobians) is compared by its chi^2 only: two twin runs at 1e-12 / 1e-14 end 4e-4 apart there (profiles/r03y_soak_trial52_replay.log)
+            print("          second request with the returned estimates (history carried: first %d, second %d): GN %d/%d stop %s/%s  cg %s (twin %s)  max vertex diff %.2e  %s"
+                  % (rw0["history_carried"], rw["history_carried"], rw["iters"], refw["iters"], rw["stop"], refw["stop"], list(map(int, rw["cg_iters"])), list(map(int, refw["cg_iters"])), dw, "ok" if okw else "MISMATCH"), flush=True)
+            if not okw:
+                sys.exit(1)
     finally:
         if fresh_handles:
             o.close()

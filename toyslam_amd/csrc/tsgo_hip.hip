@@ -733,8 +733,9 @@ template <typename T> struct Engine : IEngine {
         const size_t n = (size_t)pr.P * 3;
         if ((size_t)n_prev * n > carry_cap) {
             if (carry_dev) { (void)hipFree(carry_dev); carry_dev = nullptr; carry_cap = 0; }
-            HIP_OK(hipMalloc((void**)&carry_dev, (size_t)kMaxWarm * n * sizeof(T)));
-            carry_cap = (size_t)kMaxWarm * n;
+            const size_t want = (size_t)kMaxWarm * (n + n / 4);      // a growing graph comes back a little larger every time
+            HIP_OK(hipMalloc((void**)&carry_dev, want * sizeof(T)));
+            carry_cap = want;
         }
         for (int j = 0; j < n_prev; ++j) HIP_OK(hipMemcpyAsync(carry_dev + (size_t)j * n, hist[j], n * sizeof(T), hipMemcpyDeviceToDevice, stream));
         std::vector<T> e((size_t)kMaxWarm * nbC);

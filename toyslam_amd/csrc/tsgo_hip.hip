@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <condition_variable>
@@ -654,6 +655,14 @@ template <typename T> struct Engine : IEngine {
         const size_t o_p = 0, o_l = o_p + 4 * Sp, o_o = o_l + 4 * Sl, o_ps = o_o + 9 * So, o_th = o_ps + 4 * P, o_lm = o_th + P, total = o_lm + (size_t)kLmRec * std::max<size_t>(L, 1);
         if (int rc = stage_reserve(total)) return rc;
         const size_t nE = (size_t)g.n_edges;
+        static const bool timing = getenv("TSGO_STAGE_TIMING") != nullptr;
+        auto t_last = std::chrono::steady_clock::now();
+        auto lap = [&](const char* what) {
+            if (!timing) return;
+            const auto n = std::chrono::steady_clock::now();
+            std::fprintf(stderr, "[stage] %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(n - t_last).count());
+            t_last = n;
+        };
         // per LM edge: its four static values, once (a cos and a sin each), then scattered into both groupings
         std::vector<double>& ev = lm_values; if (ev.size() < 4 * nE) ev.resize(4 * nE);      // grow-only across requests
         parallel_chunks((int)nE, [&](int, int b, int e) {
@@ -670,31 +679,42 @@ template <typename T> struct Engine : IEngine {
                 }
             });
         };
+        lap("per-edge LM values");
         lm_table(pr.by_pose, stage + o_p);
         lm_table(pr.by_lm, stage + o_l);
-        int bad_edge = -1;
-        for (size_t k = 0; k < So; ++k) {
-            const uint32_t ed = pr.odom.edge[k];
+        lap("LM tables into staging");
+        std::atomic<int> bad_edge{INT32_MAX};
+        parallel_chunks((int)So, [&](int, int b, int e) {
             T* dst = stage + o_o;
-            if (ed == kNoEdge) { for (int m = 0; m < 9; ++m) dst[(size_t)m * So + k] = T(0); continue; }
-            double inv[9];
-            if (!invert3(g.e_meas + 9 * (size_t)ed, inv)) { bad_edge = (int)ed; break; }
-            for (int m = 0; m < 6; ++m) dst[(size_t)(OD_MI0 + m) * So + k] = (T)inv[m];
-            for (int m = 0; m < 3; ++m) dst[(size_t)(OD_W0 + m) * So + k] = (T)g.e_inf[3 * (size_t)ed + m];
-        }
-        if (bad_edge >= 0) return set_error(-2, "tsgo_set_graph: ODOM edge " + std::to_string(bad_edge) + " has a singular measurement matrix");
-        for (size_t i = 0; i < P; ++i) {
-            const double* v = g.v_pos + 3 * (size_t)pr.pose_vertex[i];
-            if (host_state) { pr.pose_xyt[3 * i] = v[0]; pr.pose_xyt[3 * i + 1] = v[1]; pr.pose_xyt[3 * i + 2] = v[2]; }
-            stage[o_ps + 4 * i] = (T)v[0]; stage[o_ps + 4 * i + 1] = (T)v[1]; stage[o_ps + 4 * i + 2] = (T)std::cos(v[2]); stage[o_ps + 4 * i + 3] = (T)std::sin(v[2]);
-            stage[o_th + i] = (T)v[2];
-        }
-        std::fill(stage + o_lm, stage + o_lm + (size_t)kLmRec * std::max<size_t>(L, 1), T(0));
-        for (size_t l = 0; l < L; ++l) {
-            const double* v = g.v_pos + 3 * (size_t)pr.lm_vertex[l];
-            if (host_state) { pr.lm_xy[2 * l] = v[0]; pr.lm_xy[2 * l + 1] = v[1]; }
-            stage[o_lm + l * kLmRec] = (T)v[0]; stage[o_lm + l * kLmRec + 1] = (T)v[1];
-        }
+            for (size_t k = (size_t)b; k < (size_t)e; ++k) {
+                const uint32_t ed = pr.odom.edge[k];
+                if (ed == kNoEdge) { for (int m = 0; m < 9; ++m) dst[(size_t)m * So + k] = T(0); continue; }
+                double inv[9];
+                if (!invert3(g.e_meas + 9 * (size_t)ed, inv)) { int seen = bad_edge.load(); while ((int)ed < seen && !bad_edge.compare_exchange_weak(seen, (int)ed)) {} continue; }
+                for (int m = 0; m < 6; ++m) dst[(size_t)(OD_MI0 + m) * So + k] = (T)inv[m];
+                for (int m = 0; m < 3; ++m) dst[(size_t)(OD_W0 + m) * So + k] = (T)g.e_inf[3 * (size_t)ed + m];
+            }
+        }, 4096);
+        if (bad_edge.load() != INT32_MAX) return set_error(-2, "tsgo_set_graph: ODOM edge " + std::to_string(bad_edge.load()) + " has a singular measurement matrix");
+        parallel_chunks((int)P, [&](int, int b, int e) {
+            for (size_t i = (size_t)b; i < (size_t)e; ++i) {
+                const double* v = g.v_pos + 3 * (size_t)pr.pose_vertex[i];
+                if (host_state) { pr.pose_xyt[3 * i] = v[0]; pr.pose_xyt[3 * i + 1] = v[1]; pr.pose_xyt[3 * i + 2] = v[2]; }
+                stage[o_ps + 4 * i] = (T)v[0]; stage[o_ps + 4 * i + 1] = (T)v[1]; stage[o_ps + 4 * i + 2] = (T)std::cos(v[2]); stage[o_ps + 4 * i + 3] = (T)std::sin(v[2]);
+                stage[o_th + i] = (T)v[2];
+            }
+        }, 4096);
+        if (L == 0) std::fill(stage + o_lm, stage + o_lm + (size_t)kLmRec, T(0));
+        parallel_chunks((int)L, [&](int, int b, int e) {
+            for (size_t l = (size_t)b; l < (size_t)e; ++l) {
+                const double* v = g.v_pos + 3 * (size_t)pr.lm_vertex[l];
+                if (host_state) { pr.lm_xy[2 * l] = v[0]; pr.lm_xy[2 * l + 1] = v[1]; }
+                T* rec = stage + o_lm + l * kLmRec;
+                rec[0] = (T)v[0]; rec[1] = (T)v[1];
+                for (int m = 2; m < kLmRec; ++m) rec[m] = T(0);
+            }
+        }, 4096);
+        lap("ODOM planes, state");
         auto put = [&](T* dst, size_t off, size_t n) -> int { if (n) HIP_OK(hipMemcpyAsync(dst, stage + off, n * sizeof(T), hipMemcpyHostToDevice, stream)); return 0; };
         if (int rc = put(st_p, o_p, 4 * Sp)) return rc;
         if (int rc = put(st_l, o_l, 4 * Sl)) return rc;
@@ -702,6 +722,7 @@ template <typename T> struct Engine : IEngine {
         if (int rc = put(ps, o_ps, 4 * P)) return rc;
         if (int rc = put(theta, o_th, P)) return rc;
         if (int rc = put(lmrec, o_lm, (size_t)kLmRec * std::max<size_t>(L, 1))) return rc;
+        if (timing) { HIP_OK(hipStreamSynchronize(stream)); lap("copies to the device (waited for)"); }
         return 0;       // the caller synchronises the stream before the staging buffer is touched again
     }
 

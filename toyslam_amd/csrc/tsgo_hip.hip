@@ -226,6 +226,8 @@ template <typename T> struct Engine : IEngine {
     hipGraphExec_t cg_graph = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int predicted_cg = 0;
+    static constexpr int kAgeSlots = 16;
+    int iters_by_age[kAgeSlots] = {};      // PCG iterations of the last solve that ran on a hierarchy of that age (do_solve_once's burst)
     // multigrid preconditioner.  Edge-sharded runs use it too: every rank holds the whole hierarchy (patterns from the whole graph,
     // level-0 blocks all-reduced, everything below computed redundantly); only the level-0 contribution lists are per shard
     bool amg_on = false;
@@ -728,7 +730,7 @@ template <typename T> struct Engine : IEngine {
 
     // solver state a fresh engine starts from: whatever was learnt on the previous graph must not leak into this one
     int reset_solver_state() {
-        have_prev = false; n_prev = 0; n_tested = 0; carried = false; predicted_cg = 0; lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
+        have_prev = false; n_prev = 0; n_tested = 0; carried = false; predicted_cg = 0; std::fill(iters_by_age, iters_by_age + kAgeSlots, 0); lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
         const T one = 1;
         { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
         { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
@@ -1425,7 +1427,10 @@ template <typename T> struct Engine : IEngine {
         // two between solves, the burst aims one iteration past the prediction (a solve on a fresh hierarchy is predicted
         // by the last fresh one, an aged one by the previous solve + 1); block-Jacobi counts are in the thousands and
         // drift, so that burst stops at 90 %.
-        const int pred = amg_on ? (hier_age == 0 && iters_fresh > 0 ? iters_fresh : predicted_cg + 1) : predicted_cg;
+        // Under the lag rule the counts repeat from one hierarchy to the next (15 15 16 17 | 15 15 16 17 at 100k poses): the best
+        // predictor of a solve is the solve of the same age on the previous hierarchy.
+        const int by_age = (amg_on && hier_age >= 0 && hier_age < kAgeSlots) ? iters_by_age[hier_age] : 0;
+        const int pred = amg_on ? (by_age > 0 ? by_age : (hier_age == 0 && iters_fresh > 0 ? iters_fresh : predicted_cg + 1)) : predicted_cg;
         int burst = amg_on ? std::max(1, (pred + 1 + ch - 1) / ch) : std::max(1, (int)(0.9 * pred) / ch);
         static const bool timing = getenv("TSGO_SOLVE_TIMING") != nullptr;
         const auto w0 = std::chrono::steady_clock::now();
@@ -1446,6 +1451,7 @@ template <typename T> struct Engine : IEngine {
         }
         *iters = h_state->iters; *fail = h_state->fail;
         predicted_cg = h_state->iters;
+        if (amg_on && hier_age >= 0 && hier_age < kAgeSlots) iters_by_age[hier_age] = h_state->fail ? 0 : h_state->iters;
         return 0;
     }
 

@@ -162,6 +162,13 @@ struct Twin {
             if (explicit0) { amgtwin::Hierarchy::spmv(amg.levels[0].A, hier.A[0], z, s0); return; }
             schur_lm(z); schur_pose(z, s0); allreduce(s0.data(), (int64_t)s0.size());
         };
+        static const bool additive0 = getenv("TSGO_TWIN_ADDITIVE0") != nullptr;      // research: M^-1 = w D^-1 + P Mc^-1 P^T, no level-0 product in the cycle
+        if (additive0) {
+            hier.restrict_to(0, r, hier.r[1]);
+            hier.cycle(1);
+            hier.prolong_add(0, hier.z[1], z);
+            return;
+        }
         cycle_product();
         for (size_t k = 0; k < s0.size(); ++k) res0[k] = r[k] - s0[k];
         hier.restrict_to(0, res0, hier.r[1]);

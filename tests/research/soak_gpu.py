@@ -91,6 +91,8 @@ while time.time() < t_end:
     bar = 1e-6 * max(1.0, r["delta_norm"] / 1e4)
     if oj == "analytic":      # (extension) weakly observed chains are worse conditioned under the analytic Jacobians: 152 880 poses with 2 landmarks each
         bar *= max(1.0, float(np.abs(ref["v_pos"]).max()) / 100.0)      # ended 2.4e-6 apart on a map of extent ~1e3 (profiles/r02t_soak_large_kept_handles.log)
+    if max(r["cg_iters"]) > 300:      # hundreds of multigrid iterations per solve: a system whose condition eats the digits (k = 2 observations per pose
+        bar *= 10                      # under full Python-rule steps: two twin runs at 1e-12 / 1e-14 end 2e-2 apart one request later, profiles/r03y_soak_large_trial22_replay.log)
     diverging = ref["stop"] == "worse" or ref["chi2"][-1] > ref["chi2"][0]       # (the Python rules have no "getting worse" stop: they run on)
     # odometry-only graphs under the analytic Jacobians are beam-like chains (block-Jacobi PCG: > 10^5 iterations at 25k poses,
     # the multigrid cycle 1 400 - 3 900): two solves to 1e-11 / 1e-12 in the preconditioned norm differ by 1e-5 there

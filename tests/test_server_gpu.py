@@ -174,6 +174,45 @@ def test_same_structure_then_a_grown_graph_on_one_connection(server):
     assert proc.poll() is None
 
 
+def test_a_connections_next_request_continues_from_the_solver_history_of_its_last_one():
+    """SURVEY 8f rank 2 ("warm-starting PCG across requests").  The server runs tsgo_config.warm_requests by default (trailing
+    argument WARM_REQUESTS, 0 switches it off): a front-end that sends back the estimates it was returned gets the same answer in
+    fewer PCG iterations — the server's own log line counts them — and a grown graph sent next is still answered correctly."""
+    import re
+    from toyslam_amd import synth
+    from toyslam_amd.graph import GraphArrays
+    big = synth.make(3300, 8, seed=23).rounded_to_wire()
+    g0 = util.first_poses(big, 3000)
+    counts, replies = {}, {}
+    for warm in ("1", "0"):
+        port, proc = _start(8, "64", "1e-10", "0", "1", "cpp", "constant", warm)
+        try:
+            with socket.create_connection(("127.0.0.1", port)) as s:
+                v0 = remote.bytes_to_vertices(_roundtrip(s, remote.graph_to_bytes(g0)), g0)
+                g1 = GraphArrays(g0.v_id, g0.v_type, v0, g0.e_type, g0.e_ids, g0.e_meas, g0.e_inf, g0.fixed)
+                v1 = remote.bytes_to_vertices(_roundtrip(s, remote.graph_to_bytes(g1)), g1)
+                at = {int(i): k for k, i in enumerate(g1.v_id)}
+                vp = big.v_pos.copy()
+                for k, i in enumerate(big.v_id):
+                    if int(i) in at:
+                        vp[k] = v1[at[int(i)]]
+                g2 = GraphArrays(big.v_id, big.v_type, vp, big.e_type, big.e_ids, big.e_meas, big.e_inf, big.fixed)
+                v2 = remote.bytes_to_vertices(_roundtrip(s, remote.graph_to_bytes(g2)), g2)
+        finally:
+            _stop(proc)
+        out = proc.stdout.read()
+        counts[warm] = [int(m) for m in re.findall(r"pcg_iters=(\d+)", out)][-3:]        # (the warm-up solve logs nothing)
+        replies[warm] = (v0, v1, v2, g1, g2)
+    assert len(counts["1"]) == 3 and len(counts["0"]) == 3, counts
+    assert counts["1"][0] == counts["0"][0]                      # a connection's first request has nothing to continue from
+    assert counts["1"][1] < counts["0"][1], counts               # the same structure with the returned estimates: warm
+    for a, b, g in zip(replies["1"][:3], replies["0"][:3], (g0, replies["1"][3], replies["1"][4])):
+        assert util.max_vertex_diff(a, b, g.v_type) < 2e-6       # same answers (f32 on the wire)
+    ref = oracle.sparse_optimize(util.to_oracle(replies["1"][4]), 8, pcg_tol=1e-12, precond="amg")
+    assert util.max_vertex_diff(replies["1"][2], ref["v_pos"], big.v_type) < 1e-4
+    print("PCG iterations per request (first / same structure again / grown): warm_requests on %s, off %s" % (counts["1"], counts["0"]))
+
+
 def test_trailing_arguments_select_the_python_rules_and_the_analytic_odometry_jacobians():
     """The server's optional trailing arguments (after the reference's five): PRECISION PCG_TOL DEVICE ENGINES RULES ODOM_JACOBIAN.
     `python:0.5 analytic` must give what the in-process handle gives with rules="python", lr=0.5, odom_jacobian="analytic" —

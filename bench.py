@@ -236,6 +236,17 @@ def main():
                 shares[KERNELS[which]] = {"launches_per_iteration": 0, "us_back_to_back": us, "us_in_situ": us, "algorithmic_bytes_per_launch": nbytes,
                                           "launches_per_step": 1.0, "us_per_step": us, "us_rocprof_stats": None, "achieved_GBps": nbytes / (us * 1e-6) / 1e9,
                                           "frac_of_hbm_peak": nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "where": ["linearisation (timed back to back)"]}
+        # What bounds a launch at this size: a floor of dependent round trips (arguments -> row bounds -> indices -> gathered operand ->
+        # store: the shortest kernels of the iteration, < 0.5 MB, take 3.5-4 us) plus the bytes the memory side really moves (PMC
+        # where a committed digest has the symbol, else the algorithmic figure) at the rate an MI355X streams in practice
+        # (MI355X_MICROARCH.md: 6.29 TB/s copy; 6.0 used).  us_latency_model / us_in_situ near 1 = the kernel is on that line.
+        FLOOR_US, STREAM_GBS = 3.7, 6000.0
+        for name, k in shares.items():
+            if not k["launches_per_iteration"]:
+                continue
+            moved = pmc_traffic(name, ARGS.workload, ARGS.precision) or k["algorithmic_bytes_per_launch"]
+            k["us_latency_model"] = FLOOR_US + moved / (STREAM_GBS * 1e9) * 1e6
+        model_iter = sum(k["us_latency_model"] * k["launches_per_iteration"] for k in shares.values() if k.get("us_latency_model"))
         us_setup = opt.time_kernel(6, reps=5)[0] if amg else None
         conv = None
         if not ARGS.no_conv:
@@ -308,6 +319,9 @@ def main():
                                            "frac": b_cg / (us_pcg * 1e-6) / 1e9 / HBM_PEAK_GBS,
                                            "note": "the byte model prices ONE block-SpMV + vector passes; a multigrid-preconditioned iteration runs three level-0 products and the coarse levels"},
                          "us_per_pcg_iteration": us_pcg,
+                         "latency_model": {"us_per_pcg_iteration": model_iter, "floor_us_per_launch": 3.7, "stream_GBps": 6000.0,
+                                           "launches_per_pcg_iteration": len(prof),
+                                           "note": "sum over the iteration's launches of (3.7 us of dependent round trips + memory-side bytes / 6 TB/s); kernels[*].us_latency_model per symbol"},
                          "ms_solve_outside_iterations": ms_solve / ARGS.steps - n_cg * us_pcg * 1e-3,
                          "us_multigrid_numeric_setup": us_setup},
         }

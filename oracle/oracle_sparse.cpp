@@ -374,6 +374,7 @@ struct Twin {
     // Gauss-Newton iteration; PCG then starts from x0 = (1 - step) * warm, the un-taken remainder of that step
     // (r = b~ - S x0), and gamma_ref = gamma * (b^T D^-1 b) / (r0^T D^-1 r0) keeps the rule relative to b~.
     double gamma_ref = 0, bdb = 0, rdr_start = 0;
+    const std::deque<std::vector<double>>* gal_hist = nullptr; int gal_m = 0;      // research: TSGO_TWIN_GALERKIN
     double linearize(const std::vector<double>* warm = nullptr) {
         lin_lm(); lin_pose();
         // gauge of owned poses goes into the partial so that it is summed exactly once across shards
@@ -382,6 +383,41 @@ struct Twin {
         double g0 = finalize();
         bdb = rdr_start = g0;           // b~^T D^-1 b~: what the multigrid PCG's stopping rule measures against (k_cg_step)
         double scale = 1;
+        // research (TSGO_TWIN_GALERKIN=m): x0 = the S-norm-optimal combination of the last m deltas (m products with THIS linearisation's S,
+        // an m x m system) instead of the polynomial continuation; profiles/r03z_galerkin_warm_start_twin.txt
+        std::vector<double> xg;
+        if (warm && gal_hist && gal_m > 0 && !gal_hist->empty()) {
+            // basis: the polynomial prediction itself (TSGO_TWIN_GALERKIN_POLY=1) + the newest deltas
+            static const bool with_poly = getenv("TSGO_TWIN_GALERKIN_POLY") != nullptr;
+            std::vector<std::vector<double>> basis;
+            if (with_poly) { basis.push_back(*warm); for (double& v : basis.back()) v *= (1.0 - step); }
+            for (size_t j = 0; j < gal_hist->size() && (int)basis.size() < gal_m; ++j) basis.push_back((*gal_hist)[j]);
+            const std::vector<std::vector<double>>* gal_basis = &basis;
+            const int m = (int)basis.size();
+            std::vector<std::vector<double>> q(m, std::vector<double>((size_t)P * 3 + 1));
+            for (int j = 0; j < m; ++j) { const std::vector<double>& d = basis[j]; schur_lm(d); q[j][(size_t)P * 3] = schur_pose(d, q[j]); allreduce(q[j].data(), (int64_t)q[j].size()); }
+            std::vector<double> G((size_t)m * m), rhs(m), c(m, 0.0);
+            for (int i = 0; i < m; ++i) {
+                const std::vector<double>& d = (*gal_basis)[i];
+                double t = 0; for (int k = 0; k < 3 * P; ++k) t += d[k] * r[k];
+                rhs[i] = t;
+                for (int j = 0; j < m; ++j) { double g = 0; for (int k = 0; k < 3 * P; ++k) g += d[k] * q[j][k]; G[(size_t)i * m + j] = g; }
+            }
+            // Gaussian elimination with partial pivoting (m <= 6); a nearly dependent basis is caught by the pivot test
+            std::vector<double> A = G, bb = rhs; bool ok = true;
+            for (int col = 0; col < m && ok; ++col) {
+                int piv = col; for (int rw = col + 1; rw < m; ++rw) if (std::fabs(A[(size_t)rw * m + col]) > std::fabs(A[(size_t)piv * m + col])) piv = rw;
+                if (std::fabs(A[(size_t)piv * m + col]) < 1e-14 * std::fabs(G[0])) { ok = false; break; }
+                if (piv != col) { for (int k = 0; k < m; ++k) std::swap(A[(size_t)piv * m + k], A[(size_t)col * m + k]); std::swap(bb[piv], bb[col]); }
+                for (int rw = col + 1; rw < m; ++rw) { const double f = A[(size_t)rw * m + col] / A[(size_t)col * m + col]; for (int k = col; k < m; ++k) A[(size_t)rw * m + k] -= f * A[(size_t)col * m + k]; bb[rw] -= f * bb[col]; }
+            }
+            if (ok) {
+                for (int rw = m - 1; rw >= 0; --rw) { double t = bb[rw]; for (int k = rw + 1; k < m; ++k) t -= A[(size_t)rw * m + k] * c[k]; c[rw] = t / A[(size_t)rw * m + rw]; }
+                xg.assign((size_t)P * 3, 0.0);
+                for (int j = 0; j < m; ++j) for (int k = 0; k < 3 * P; ++k) xg[k] += c[j] * (*gal_basis)[j][k] / (1.0 - step);
+                warm = &xg;
+            }
+        }
         if (warm && warm->size() == x.size()) {
             for (size_t k = 0; k < x.size(); ++k) x[k] = (1.0 - step) * (*warm)[k];
             std::vector<double> buf((size_t)P * 3 + 1);
@@ -574,6 +610,7 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
     if (precond == 1 && !tw.enable_amg(g).empty()) return -5;
     std::memcpy(v_pos_out, v_pos, sizeof(double) * 3 * (size_t)nV);
     double prevErr = -1; int penalty = 0;
+    static const int galerkin_m = getenv("TSGO_TWIN_GALERKIN") ? atoi(getenv("TSGO_TWIN_GALERKIN")) : 0;
     constexpr int kTwinMaxWarm = 6; constexpr double kTwinWarmMargin = 4;      // kMaxWarm, kWarmMargin of tsgo_kernels.h
     std::deque<std::vector<double>> hist;      // pose deltas of the last solves, newest first
     double warm_err[kTwinMaxWarm] = {}; int n_tested = 0;
@@ -601,6 +638,7 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
             for (int j = 1; j <= m; ++j) { const double c = coeff(m, j) / a; for (size_t k = 0; k < xw.size(); ++k) xw[k] += c * hist[j - 1][k]; }   // linearize() scales by a
         }
         const std::vector<double>* warm = xw.empty() ? nullptr : &xw;
+        tw.gal_hist = &hist; tw.gal_m = galerkin_m;
         double gamma0;
         if (py) {          // as Engine::optimize: linearise with the lambda a non-increasing chi^2 gives, repeat when it did rise
             tw.lambda = std::max(lam / 1.1, 1e-6);

@@ -98,7 +98,7 @@ while time.time() < t_end:
     # the multigrid cycle 1 400 - 3 900): two solves to 1e-11 / 1e-12 in the preconditioned norm differ by 1e-5 there
     beam = shape.startswith("pose graph") and oj == "analytic"
     ok = r["iters"] == ref["iters"] and r["stop"] == ref["stop"] and np.allclose(r["chi2"], ref["chi2"], rtol=1e-6 if (diverging or beam) else 1e-8) \
-        and d < (bar * 10 if diverging else (1e-4 if beam else bar))
+        and (diverging or d < (1e-4 if beam else bar))      # a diverging run (chi^2 rising; seed 51 trial 87: 1.1e4 -> 9.5e6 under full steps) is compared by its chi^2: two device runs at 1e-11 / 1e-13 end 1e-3 apart (profiles/r03y_soak_trial87_replay.log)
     worst = max(worst, d); most_cg = max(most_cg, int(max(r["cg_iters"]))); fallbacks += int(r["fallbacks"])
     print("trial %3d %-18s n=%6d k=%2d closures=%4d fixed=%d: GN %d/%d stop %s/%s  cg %s  max vertex diff %.2e  %s"
           % (trial, shape, n, k, lc, len(fx), r["iters"], ref["iters"], r["stop"], ref["stop"], list(map(int, r["cg_iters"])), d, "ok" if ok else "MISMATCH"), flush=True)

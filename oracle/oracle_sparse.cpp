@@ -437,7 +437,7 @@ struct Twin {
             // the coarse matrices may lag the linearisation (level 0 never does): rebuilt after kHierMaxAge solves or
             // when the last solve took kHierSlack iterations more than the first one on this hierarchy
             static const int max_age = getenv("TSGO_HIER_MAX_AGE") ? std::max(1, atoi(getenv("TSGO_HIER_MAX_AGE"))) : 4;      // = kHierMaxAge (tsgo_hip.hip)
-            const bool refresh = hier_age < 0 || hier_age >= max_age || iters_last > iters_fresh + 2;
+            const bool refresh = hier_age < 0 || hier_age >= (n_lin < 6 ? std::min(max_age, 2) : max_age) || iters_last > iters_fresh + 2;      // kYoungLins, kYoungMaxAge (tsgo_hip.hip)
             if (!amg.levels.empty() && refresh) { build_schur_blocks(); hier.setup_from_level0(); hier_age = 0; }
             ++n_lin;
             amg_apply();

@@ -145,6 +145,7 @@ constexpr double kMediumPairList = 6;   // Galerkin products whose average pair 
 constexpr double kLongPairList = 16;    // ... longer than this among 16 lanes ...
 constexpr double kVeryLongPairList = 200; // ... or a whole wavefront
 constexpr int kHierMaxAge = 4;          // a multigrid hierarchy serves at most this many consecutive linearisations (2: 4.32, 3: 4.25, 4: 4.16, 6: 4.16 ms per step at 100k poses, profiles/r03h_*) ...
+constexpr int kYoungLins = 6, kYoungMaxAge = 2;   // ... a graph's first linearisations: two per hierarchy at most (do_linearize)
 constexpr int kHierSlack = 2;           // ... and is rebuilt as soon as a solve needs more than this many iterations over its first
 constexpr int kPackedCycleMaxIters = 64; // a multigrid solve that needs more iterations than this is on an ill-conditioned graph: its cycle leaves the packed halves for f32
 constexpr int kHierFreshAbove = 64;     // ... and at every linearisation while solves take more iterations than this (a build costs about four)
@@ -243,6 +244,7 @@ template <typename T> struct Engine : IEngine {
     T* h_rho = nullptr;                 // pinned
     std::vector<double> omega_host;    // smoother damping per level (diagnostics)
     int lin_count = 0;
+    int n_lins = 0;                    // linearisations of this graph so far (reset with the solver state)
     int hier_age = -1, hier_max_age = kHierMaxAge, hier_slack = kHierSlack, iters_fresh = 0, iters_last = 0;   // -1: no valid hierarchy
     T* hist[kMaxWarm] = {};            // pose deltas of the last solves, newest first (warm start)
     bool have_prev = false;            // hist[0] holds the pose delta of the previous solve
@@ -730,7 +732,7 @@ template <typename T> struct Engine : IEngine {
 
     // solver state a fresh engine starts from: whatever was learnt on the previous graph must not leak into this one
     int reset_solver_state() {
-        have_prev = false; n_prev = 0; n_tested = 0; carried = false; predicted_cg = 0; std::fill(iters_by_age, iters_by_age + kAgeSlots, 0); lin_count = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
+        have_prev = false; n_prev = 0; n_tested = 0; carried = false; predicted_cg = 0; std::fill(iters_by_age, iters_by_age + kAgeSlots, 0); lin_count = 0; n_lins = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
         const T one = 1;
         { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
         { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
@@ -789,7 +791,7 @@ template <typename T> struct Engine : IEngine {
             if (flat) { if (id <= max_id) j = table[id]; } else { auto it = by_id.find(id); if (it != by_id.end()) j = it->second; }
             src[(size_t)i] = j; found += j >= 0;
         }
-        if (2 * (int64_t)found < (int64_t)std::min(pr.P, carry.P)) return 0;      // another graph altogether: nothing to continue
+        if (2 * (int64_t)found < (int64_t)std::max(pr.P, carry.P)) return 0;      // another graph altogether (or one grown beyond recognition): nothing to continue
         int* src_dev = nullptr;
         if (int rc = upload_i32(&src_dev, src)) return rc;
         const size_t n = (size_t)carry.P * 3;
@@ -799,7 +801,7 @@ template <typename T> struct Engine : IEngine {
         for (int m = 0; m < kMaxWarm; ++m) e[(size_t)m * nbC] = (T)carry.err[m];
         if (int rc = copy_sync(warm_err, e.data(), e.size() * sizeof(T), hipMemcpyHostToDevice)) return rc;
         HIP_OK(hipStreamSynchronize(stream));
-        have_prev = true; n_prev = n_old; n_tested = carry.n_tested; carried = true; ++n_carried;
+        have_prev = true; n_prev = n_old; n_tested = carry.n_tested; carried = true; ++n_carried;      // (a grown graph IS young where it grew: n_lins stays 0)
         return 0;
     }
 
@@ -835,7 +837,7 @@ template <typename T> struct Engine : IEngine {
         const bool keep = cfg.warm_requests && have_prev && n_prev > 0;      // same structure, same numbering: the history stays where it is
         const int keep_prev = n_prev, keep_tested = n_tested;
         if (int rc = reset_solver_state()) return rc;
-        if (keep) { have_prev = true; n_prev = keep_prev; n_tested = keep_tested; carried = true; ++n_carried; }
+        if (keep) { have_prev = true; n_prev = keep_prev; n_tested = keep_tested; carried = true; ++n_carried; n_lins = kYoungLins; }      // a continued graph is not a young one
         HIP_OK(hipStreamSynchronize(stream));
         return 0;
     }
@@ -1301,7 +1303,12 @@ template <typename T> struct Engine : IEngine {
             // The Galerkin hierarchy is a preconditioner, not the operator: level 0 (the Schur products, its diagonal
             // inverse) is always the current linearisation, the coarse matrices may lag.  They are rebuilt when they
             // have served hier_max_age solves or the last solve took kHierSlack iterations more than the first one did.
-            const bool refresh = hier_age < 0 || hier_age >= hier_max_age || iters_last > iters_fresh + hier_slack || iters_last > kHierFreshAbove;
+            // ... and a young graph's linearisations move faster than a hierarchy ages (Huber weights switch by the thousand in the first
+            // steps from a front-end's estimates: 22 / 23 / 30 iterations on one hierarchy where fresh ones take 22 / 19 / 18 at 100k poses):
+            // the first kYoungLins linearisations of a graph share a hierarchy between two at most (profiles/r03z_early_iterations.txt)
+            const int max_age = n_lins < kYoungLins ? std::min(hier_max_age, kYoungMaxAge) : hier_max_age;
+            ++n_lins;
+            const bool refresh = hier_age < 0 || hier_age >= max_age || iters_last > iters_fresh + hier_slack || iters_last > kHierFreshAbove;
             if (refresh) {
                 if (int rc = launch_amg_setup()) return rc;
                 hier_age = 0;
@@ -1354,7 +1361,7 @@ template <typename T> struct Engine : IEngine {
             // is dropped and the solve starts cold (every shard reads the same all-reduced numbers and decides alike).
             T gs = 0;
             if (int rc = copy_sync(&gs, gscale_dev, sizeof(T), hipMemcpyDeviceToHost)) return rc;
-            if (!(gs > T(1))) { launch_finalize(); have_prev = false; n_prev = 0; n_tested = 0; ++n_carry_dropped; }
+            if (!(gs > T(1))) { launch_finalize(); have_prev = false; n_prev = 0; n_tested = 0; ++n_carry_dropped; n_lins = 1; }      // ... and the graph is a young one after all
         }
         carried = false;
         if (int rc = do_solve_once(iters, fail)) return rc;

@@ -155,7 +155,7 @@ def main():
     n_edges = len(g.e_type)
     opt = HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol,
                        rank=rank if shard else 0, world=world if shard else 1,
-                       use_graphs=not ARGS.no_graphs, lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
+                       use_graphs=(False if ARGS.no_graphs else (True if ARGS.graphs else "auto")), lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
                        preconditioner=ARGS.precond, warm_start=ARGS.warm_start, cycle_level0="explicit" if explicit_cycle else "implicit", cycle_storage=ARGS.cycle_storage)
     if ARGS.force_collective and world == 1:          # research: the sharded code path (eager launches + RCCL calls) with a one-rank communicator
         with stdout_to_stderr():
@@ -181,9 +181,10 @@ def main():
     barrier()
     t0 = time.perf_counter()
     ms_lin = ms_solve = ms_upd = 0.0
+    graph_replay = False
     for _ in range(ARGS.steps):
         r = opt.optimize(1); chi2 += list(r["chi2"]); cg += list(r["cg_iters"])
-        ms_lin += r["ms_linearize"]; ms_solve += r["ms_solve"]; ms_upd += r["ms_update"]; ms_setup = r["ms_setup"]
+        ms_lin += r["ms_linearize"]; ms_solve += r["ms_solve"]; ms_upd += r["ms_update"]; ms_setup = r["ms_setup"]; graph_replay = graph_replay or r["graph_replay"]
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -295,7 +296,7 @@ def main():
                        "parallelism": ("BASELINE config 4: one graph edge-sharded x%d (landmark ranges), replicated multigrid hierarchy, %s" % (world, "in-cycle products on the replicated explicit level-0 matrix: one RCCL all-reduce per PCG iteration" if explicit_cycle else "RCCL all-reduce per Schur product (three per PCG iteration)")) if shard else
                                       ("request-parallel: %d independent graphs, one per GPU, no collective" % world if world > 1 else
                                        ("single GPU, collective code path forced (one-rank RCCL communicator)" if ARGS.force_collective else "single GPU")),
-                       "hipgraph": (not ARGS.no_graphs) and not shard and not ARGS.force_collective},
+                       "hipgraph": graph_replay, "launch_mode": "tsgo_config.use_graphs = %d (%s)" % (0 if ARGS.no_graphs else (1 if ARGS.graphs else 2), "hipGraph replay" if graph_replay else "eager launches")},
             "gn_iters_per_s": ARGS.steps / dt,
             "pcg_iters_per_gn_iter": n_cg,
             "chi2_first_last": [chi2[0], chi2[-1]],
@@ -358,7 +359,8 @@ if __name__ == "__main__":
                     help="tsgo_config.cycle_storage: the V-cycle's copies of the hierarchy as packed half floats (default) or f32")
     ap.add_argument("--force-collective", dest="force_collective", action="store_true",
                     help="N = 1: give the engine a one-rank RCCL communicator so that it takes the sharded code path (eager launches, all-reduce calls)")
-    ap.add_argument("--no-graphs", dest="no_graphs", action="store_true")
+    ap.add_argument("--no-graphs", dest="no_graphs", action="store_true", help="tsgo_config.use_graphs = 0: eager launches always")
+    ap.add_argument("--graphs", dest="graphs", action="store_true", help="tsgo_config.use_graphs = 1: hipGraph replay always (default 2: eager while the host keeps ahead)")
     ap.add_argument("--no-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--no-conv", dest="no_conv", action="store_true", help="skip the 50-iteration convergence run")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0)

@@ -57,7 +57,12 @@ typedef struct tsgo_config {
     int32_t pcg_max_iters;   /* cap per Gauss-Newton iteration; default 20000 */
     int32_t lanes_per_pose;  /* 0 = auto; 1, 2, 4 or 8 lanes cooperate on one pose row */
     int32_t lanes_per_lm;    /* 0 = auto */
-    int32_t use_graphs;      /* 1 (default): replay the PCG iteration from a hipGraph */
+    int32_t use_graphs;      /* 0: every PCG iteration is launched kernel by kernel.  1: replayed from a captured hipGraph (from the second
+                                tsgo_optimize on a structure on; the capture takes 15 ms at 100k poses).  2 (default): eager launches while the host
+                                thread stays well ahead of the device — on the GPU boxes' EPYC 9575F it enqueues an iteration in 90 us, the device
+                                runs it in 217, and eager is 1-3 % faster than the replay — and the replay as soon as it does not (three bursts in
+                                a row enqueued slower than 0.7 of the device's time per iteration).  Edge-sharded runs launch eagerly
+                                whatever this says (RCCL calls sit between the kernels).  Same answers, bit for bit. */
     int32_t rank, world;     /* edge sharding: this process owns shard `rank` of `world` (default 0, 1) */
     int32_t verbose;
     int32_t preconditioner;  /* 1 (default): smoothed-aggregation multigrid V-cycle on the reduced pose system; 0: block-Jacobi on its
@@ -129,7 +134,7 @@ typedef struct tsgo_stats {
     int32_t history_carried;             /* tsgo_config.warm_requests: 1 when this run started from the solver history of the handle's previous
                                             request (kept in place or carried over by vertex id), 2 when it did and the first solve dropped it
                                             (it did not fit the new estimates), 0 otherwise */
-    int32_t pad_;
+    int32_t graph_replay;                /* 1 when this run replayed captured hipGraphs of the PCG iteration (tsgo_config.use_graphs), 0: eager launches */
 } tsgo_stats;
 
 /* Fills cfg with defaults. */

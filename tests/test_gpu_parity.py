@@ -90,10 +90,17 @@ def test_lanes_per_vertex_variants_agree_with_dense(lanes):
 
 
 @pytest.mark.parametrize("precond", ["amg", "jacobi"])
-def test_hipgraph_replay_equals_eager_launches(precond):
+def test_hipgraph_replay_equals_eager_launches(precond, monkeypatch):
+    """tsgo_config.use_graphs: 1 = captured iterations replayed (from the second tsgo_optimize on a structure), 0 = eager, 2 ("auto", the
+    default) = eager while the host thread keeps ahead of the device, replay once it has been seen not to (test hook TSGO_FORCE_HOST_SLOW:
+    the handle believes its host is slow).  Same bits every way: no atomics anywhere."""
     g = synth.make(2000, 10, seed=5)
     res = []
-    for use_graphs in (True, False):
+    for use_graphs, slow in ((True, False), (False, False), ("auto", False), ("auto", True)):
+        if slow:
+            monkeypatch.setenv("TSGO_FORCE_HOST_SLOW", "1")
+        else:
+            monkeypatch.delenv("TSGO_FORCE_HOST_SLOW", raising=False)
         o = HipOptimizer(pcg_rel_tol=1e-10, use_graphs=use_graphs, preconditioner=precond)
         try:
             o.set_graph(g)
@@ -105,9 +112,12 @@ def test_hipgraph_replay_equals_eager_launches(precond):
             res.append((r, o.vertices()))
         finally:
             o.close()
-    np.testing.assert_array_equal(res[0][0]["chi2"], res[1][0]["chi2"])       # bitwise: no atomics anywhere
-    np.testing.assert_array_equal(res[0][0]["cg_iters"], res[1][0]["cg_iters"])
-    np.testing.assert_array_equal(res[0][1], res[1][1])
+    monkeypatch.delenv("TSGO_FORCE_HOST_SLOW", raising=False)
+    assert [r["graph_replay"] for r, _ in res] == [True, False, precond == "jacobi", True], [r["graph_replay"] for r, _ in res]      # (block-Jacobi PCG is always replayed under "auto")
+    for r, v in res[1:]:
+        np.testing.assert_array_equal(res[0][0]["chi2"], r["chi2"])       # bitwise
+        np.testing.assert_array_equal(res[0][0]["cg_iters"], r["cg_iters"])
+        np.testing.assert_array_equal(res[0][1], v)
 
 
 @pytest.mark.parametrize("precond", ["amg", "jacobi"])

@@ -21,7 +21,7 @@ class tsgo_stats(C.Structure):
                 ("ms_total", C.c_double), ("ms_linearize", C.c_double), ("ms_solve", C.c_double),
                 ("ms_update", C.c_double), ("ms_setup", C.c_double), ("structure_reused", C.c_int32), ("cycle_storage_now", C.c_int32), ("lambda_last", C.c_double), ("n_pose", C.c_int64), ("n_lm", C.c_int64),
                 ("n_odom_edges", C.c_int64), ("n_lm_edges", C.c_int64), ("pcg_iters_total", C.c_int64),
-                ("pcg_fallbacks", C.c_int32), ("trace_len", C.c_int32), ("chi2_last", C.c_double), ("history_carried", C.c_int32), ("pad_", C.c_int32)]
+                ("pcg_fallbacks", C.c_int32), ("trace_len", C.c_int32), ("chi2_last", C.c_double), ("history_carried", C.c_int32), ("graph_replay", C.c_int32)]
 
 
 class tsgo_cycle_level(C.Structure):

@@ -10,7 +10,7 @@
 extern "C" void tsgo_default_config(tsgo_config* c) {
     if (!c) return;
     c->device = 0; c->precision = 64; c->pcg_rel_tol = 1e-10; c->pcg_max_iters = 20000;
-    c->lanes_per_pose = 0; c->lanes_per_lm = 0; c->use_graphs = 1; c->rank = 0; c->world = 1; c->verbose = 0; c->preconditioner = 1; c->xcd_map = 1; c->warm_start = 6; c->odom_jacobian = 0; c->reuse_structure = 1; c->rules = 0; c->lr = 0.2; c->cycle_level0 = 0; c->cycle_storage = 16; c->warm_requests = 0;
+    c->lanes_per_pose = 0; c->lanes_per_lm = 0; c->use_graphs = 2; c->rank = 0; c->world = 1; c->verbose = 0; c->preconditioner = 1; c->xcd_map = 1; c->warm_start = 6; c->odom_jacobian = 0; c->reuse_structure = 1; c->rules = 0; c->lr = 0.2; c->cycle_level0 = 0; c->cycle_storage = 16; c->warm_requests = 0;
 }
 
 extern "C" int tsgo_layout_probe(const tsgo_graph* g, int32_t rank, int32_t world, int32_t lanes_per_pose,

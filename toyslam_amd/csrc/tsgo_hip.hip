@@ -146,6 +146,7 @@ constexpr double kLongPairList = 16;    // ... longer than this among 16 lanes .
 constexpr double kVeryLongPairList = 200; // ... or a whole wavefront
 constexpr int kHierMaxAge = 4;          // a multigrid hierarchy serves at most this many consecutive linearisations (2: 4.32, 3: 4.25, 4: 4.16, 6: 4.16 ms per step at 100k poses, profiles/r03h_*) ...
 constexpr int kYoungLins = 6, kYoungMaxAge = 2;   // ... a graph's first linearisations: two per hierarchy at most (do_linearize)
+constexpr double kHostSlowFraction = 0.7;   // use_graphs = 2: an eager burst whose enqueueing takes more than this share of the device's time per iteration is too slow
 constexpr int kHierSlack = 2;           // ... and is rebuilt as soon as a solve needs more than this many iterations over its first
 constexpr int kPackedCycleMaxIters = 64; // a multigrid solve that needs more iterations than this is on an ill-conditioned graph: its cycle leaves the packed halves for f32
 constexpr int kHierFreshAbove = 64;     // ... and at every linearisation while solves take more iterations than this (a build costs about four)
@@ -227,6 +228,10 @@ template <typename T> struct Engine : IEngine {
     hipGraphExec_t cg_graph = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int predicted_cg = 0;
+    double dev_us_per_iter = 0;        // wall time of the last multigrid solve over its iterations
+    bool host_slow = false;            // use_graphs = 2: the host thread has been seen to enqueue too slowly for eager launches (do_solve_once)
+    int n_host_slow = 0;
+    bool replayed = false;             // the last tsgo_optimize replayed captured iterations (tsgo_stats.graph_replay)
     static constexpr int kAgeSlots = 16;
     int iters_by_age[kAgeSlots] = {};      // PCG iterations of the last solve that ran on a hierarchy of that age (do_solve_once's burst)
     // multigrid preconditioner.  Edge-sharded runs use it too: every rank holds the whole hierarchy (patterns from the whole graph,
@@ -1448,7 +1453,13 @@ template <typename T> struct Engine : IEngine {
                 else for (int j = 0; j < ch; ++j) if (int rc = launch_iteration(j & 1)) return rc;
                 launched += ch;
             }
-            if (timing) std::fprintf(stderr, "[tsgo] solve: %d chunk(s) enqueued at %.0f us", burst, since());
+            const double t_enq = since();
+            if (timing) std::fprintf(stderr, "[tsgo] solve: %d chunk(s) enqueued at %.0f us", burst, t_enq);
+            if (!cg_graph && amg_on && burst >= 4 && dev_us_per_iter > 0) {      // an eager burst of >= 8 iterations: was the host well ahead of the device?
+                const double host_us_per_iter = t_enq / (burst * ch);
+                if (host_us_per_iter > kHostSlowFraction * dev_us_per_iter) { if (++n_host_slow >= 3) host_slow = true; } else n_host_slow = 0;
+            }
+            if (cg_graph) replayed = true;
             burst = 1;
             HIP_OK(hipMemcpyAsync(h_state, st[0], sizeof(CgState<T>), hipMemcpyDeviceToHost, stream));
             HIP_OK(hipStreamSynchronize(stream));
@@ -1458,6 +1469,7 @@ template <typename T> struct Engine : IEngine {
         }
         *iters = h_state->iters; *fail = h_state->fail;
         predicted_cg = h_state->iters;
+        if (amg_on && h_state->iters >= 4 && !h_state->fail) dev_us_per_iter = since() / h_state->iters;      // (an upper bound: the solve's wall time over its iterations)
         if (amg_on && hier_age >= 0 && hier_age < kAgeSlots) iters_by_age[hier_age] = h_state->fail ? 0 : h_state->iters;
         return 0;
     }
@@ -1508,7 +1520,13 @@ template <typename T> struct Engine : IEngine {
     int optimize(int iterations, tsgo_stats* out) override {
         if (!have_graph_data) return set_error(-3, "tsgo_optimize: no graph set");
         HIP_OK(hipSetDevice(cfg.device));
-        if (cfg.use_graphs && !collective() && !cg_graph && optimize_calls_on_tables >= 1) { if (int rc = capture_cg_graph()) return rc; }
+        // use_graphs 1: the PCG iterations are replayed from a captured hipGraph (from the second tsgo_optimize on these tables on).  2
+        // (default): eager launches while the host thread enqueues an iteration in well under the time the device takes to run it
+        // (3 us per launch against 7 on an EPYC 9575F: eager is then 1-3 % FASTER than the replay and steadier, profiles/r03z_eager_vs_graph.txt);
+        // a host that cannot keep that distance (busy cores, a slow clock) is noticed by do_solve_once and the handle goes over to replay.
+        if (getenv("TSGO_FORCE_HOST_SLOW")) host_slow = true;      // test hook
+        const bool want_graph = cfg.use_graphs == 1 || (cfg.use_graphs == 2 && (host_slow || !amg_on));      // (block-Jacobi PCG is two short kernels per iteration, thousands of times: always replayed)
+        if (want_graph && !collective() && !cg_graph && optimize_calls_on_tables >= 1) { if (int rc = capture_cg_graph()) return rc; }
         inject_armed = true;
         ++optimize_calls_on_tables;
         tsgo_stats s; std::memset(&s, 0, sizeof(s));
@@ -1519,6 +1537,7 @@ template <typename T> struct Engine : IEngine {
         double np2_last = 0, nl2_last = 0;
         const int fallbacks0 = n_fallbacks, dropped0 = n_carry_dropped;
         const bool started_carried = carried;
+        replayed = false;
         s.stop_reason = TSGO_STOP_CAP;
         const auto wall0 = std::chrono::steady_clock::now();
         // rules = 1 (graph_optimizer.py:24-31): lambda starts at 1e-3 on every call
@@ -1582,6 +1601,7 @@ template <typename T> struct Engine : IEngine {
         }
         s.pcg_fallbacks = n_fallbacks - fallbacks0;
         s.history_carried = started_carried ? (n_carry_dropped > dropped0 ? 2 : 1) : 0;
+        s.graph_replay = replayed ? 1 : 0;
         s.cycle_storage_now = amg_on ? (cy16 ? 16 : 32) : 0;
         s.ms_total = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
         if (out) *out = s;

@@ -16,13 +16,13 @@ STOP = {0: "cap", 1: "worse", 2: "plateau", 3: "converged", 4: "solver_failed"}
 
 class HipOptimizer:
     def __init__(self, device=0, precision=64, pcg_rel_tol=1e-10, pcg_max_iters=20000, lanes_per_pose=0,
-                 lanes_per_lm=0, use_graphs=True, rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None,
+                 lanes_per_lm=0, use_graphs="auto", rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None,
                  reuse_structure=None, rules="cpp", lr=0.2, odom_jacobian="constant", cycle_level0="implicit", cycle_storage=16, warm_requests=False):
         self.lib = _lib.hip_lib()
         cfg = _lib.tsgo_config()
         self.lib.tsgo_default_config(C.byref(cfg))
         cfg.device, cfg.precision, cfg.pcg_rel_tol, cfg.pcg_max_iters = device, precision, pcg_rel_tol, pcg_max_iters
-        cfg.lanes_per_pose, cfg.lanes_per_lm, cfg.use_graphs = lanes_per_pose, lanes_per_lm, int(use_graphs)
+        cfg.lanes_per_pose, cfg.lanes_per_lm, cfg.use_graphs = lanes_per_pose, lanes_per_lm, (2 if use_graphs == "auto" else int(bool(use_graphs)))
         cfg.rank, cfg.world = rank, world
         cfg.preconditioner = {"jacobi": 0, "amg": 1}[preconditioner]
         if xcd_map is not None:
@@ -67,7 +67,7 @@ class HipOptimizer:
                     cg_iters=np.array(st.pcg_iters[:n]), delta_norm=st.last_delta_norm, ms_total=st.ms_total,
                     ms_linearize=st.ms_linearize, ms_solve=st.ms_solve, ms_update=st.ms_update, ms_setup=st.ms_setup, structure_reused=bool(st.structure_reused), lambda_last=st.lambda_last,
                     n_pose=st.n_pose, n_lm=st.n_lm, n_odom_edges=st.n_odom_edges, n_lm_edges=st.n_lm_edges,
-                    cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks, cycle_storage_now=st.cycle_storage_now, history_carried=st.history_carried)
+                    cg_total=st.pcg_iters_total, fallbacks=st.pcg_fallbacks, cycle_storage_now=st.cycle_storage_now, history_carried=st.history_carried, graph_replay=bool(st.graph_replay))
 
     def vertices(self):
         out = np.zeros((self.n_vertices, 3)) if self._v_in is None else np.ascontiguousarray(self._v_in.copy())

@@ -60,8 +60,9 @@ typedef struct tsgo_config {
     int32_t use_graphs;      /* 0: every PCG iteration is launched kernel by kernel.  1: replayed from a captured hipGraph (from the second
                                 tsgo_optimize on a structure on; the capture takes 15 ms at 100k poses).  2 (default): eager launches while the host
                                 thread stays well ahead of the device — on the GPU boxes' EPYC 9575F it enqueues an iteration in 90 us, the device
-                                runs it in 217, and eager is 1-3 % faster than the replay — and the replay as soon as it does not (three bursts in
-                                a row enqueued slower than 0.7 of the device's time per iteration).  Edge-sharded runs launch eagerly
+                                runs it in 217, and eager is 1-3 % faster than the replay — and the replay as soon as it does not (two of a
+                                structure's first three solves whose bursts took more than 0.6 of the solve's own time per iteration to enqueue: no
+                                margin; later only outright starvation, 0.95 three times in a row).  Edge-sharded runs launch eagerly
                                 whatever this says (RCCL calls sit between the kernels).  Same answers, bit for bit. */
     int32_t rank, world;     /* edge sharding: this process owns shard `rank` of `world` (default 0, 1) */
     int32_t verbose;

@@ -146,7 +146,9 @@ constexpr double kLongPairList = 16;    // ... longer than this among 16 lanes .
 constexpr double kVeryLongPairList = 200; // ... or a whole wavefront
 constexpr int kHierMaxAge = 4;          // a multigrid hierarchy serves at most this many consecutive linearisations (2: 4.32, 3: 4.25, 4: 4.16, 6: 4.16 ms per step at 100k poses, profiles/r03h_*) ...
 constexpr int kYoungLins = 6, kYoungMaxAge = 2;   // ... a graph's first linearisations: two per hierarchy at most (do_linearize)
-constexpr double kHostSlowFraction = 0.7;   // use_graphs = 2: an eager burst whose enqueueing takes more than this share of the device's time per iteration is too slow
+constexpr double kHostSlowFraction = 0.6;   // use_graphs = 2: eager launches need the host to be done enqueueing a burst well before the device is done running it.  At 100k
+                                            // poses the host needs 0.4 of the solve's time (90 of 217 us per iteration) and eager wins by 2 %; at 10k poses 0.9 (90 of 99 us):
+                                            // eager is then as fast on a good run (2.25 ms per step against 2.32) and 20-30 % slower on a bad one — replay
 constexpr int kHierSlack = 2;           // ... and is rebuilt as soon as a solve needs more than this many iterations over its first
 constexpr int kPackedCycleMaxIters = 64; // a multigrid solve that needs more iterations than this is on an ill-conditioned graph: its cycle leaves the packed halves for f32
 constexpr int kHierFreshAbove = 64;     // ... and at every linearisation while solves take more iterations than this (a build costs about four)
@@ -230,7 +232,8 @@ template <typename T> struct Engine : IEngine {
     int predicted_cg = 0;
     double dev_us_per_iter = 0;        // wall time of the last multigrid solve over its iterations
     bool host_slow = false;            // use_graphs = 2: the host thread has been seen to enqueue too slowly for eager launches (do_solve_once)
-    int n_host_slow = 0;
+    int n_host_slow = 0, n_decided = 0, n_slow_seen = 0;
+    static constexpr int kDecideSolves = 3;
     bool replayed = false;             // the last tsgo_optimize replayed captured iterations (tsgo_stats.graph_replay)
     static constexpr int kAgeSlots = 16;
     int iters_by_age[kAgeSlots] = {};      // PCG iterations of the last solve that ran on a hierarchy of that age (do_solve_once's burst)
@@ -737,7 +740,7 @@ template <typename T> struct Engine : IEngine {
 
     // solver state a fresh engine starts from: whatever was learnt on the previous graph must not leak into this one
     int reset_solver_state() {
-        have_prev = false; n_prev = 0; n_tested = 0; carried = false; predicted_cg = 0; std::fill(iters_by_age, iters_by_age + kAgeSlots, 0); lin_count = 0; n_lins = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
+        have_prev = false; n_prev = 0; n_tested = 0; carried = false; predicted_cg = 0; n_decided = 0; n_slow_seen = 0; n_host_slow = 0; std::fill(iters_by_age, iters_by_age + kAgeSlots, 0); lin_count = 0; n_lins = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
         const T one = 1;
         { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
         { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
@@ -1457,7 +1460,11 @@ template <typename T> struct Engine : IEngine {
             if (timing) std::fprintf(stderr, "[tsgo] solve: %d chunk(s) enqueued at %.0f us", burst, t_enq);
             if (!cg_graph && amg_on && burst >= 4 && dev_us_per_iter > 0) {      // an eager burst of >= 8 iterations: was the host well ahead of the device?
                 const double host_us_per_iter = t_enq / (burst * ch);
-                if (host_us_per_iter > kHostSlowFraction * dev_us_per_iter) { if (++n_host_slow >= 3) host_slow = true; } else n_host_slow = 0;
+                const double share = host_us_per_iter / dev_us_per_iter;
+                if (n_decided < kDecideSolves) {      // the structure's first solves settle it (within a bench's warm-up, a request's first iterations): no flip in mid-run
+                    n_slow_seen += share > kHostSlowFraction;
+                    if (++n_decided == kDecideSolves && 2 * n_slow_seen > kDecideSolves) host_slow = true;
+                } else if (share > 0.95) { if (++n_host_slow >= 3) host_slow = true; } else n_host_slow = 0;      // later only outright starvation (a profiler attached, cores taken away)
             }
             if (cg_graph) replayed = true;
             burst = 1;
@@ -1523,7 +1530,8 @@ template <typename T> struct Engine : IEngine {
         // use_graphs 1: the PCG iterations are replayed from a captured hipGraph (from the second tsgo_optimize on these tables on).  2
         // (default): eager launches while the host thread enqueues an iteration in well under the time the device takes to run it
         // (3 us per launch against 7 on an EPYC 9575F: eager is then 1-3 % FASTER than the replay and steadier, profiles/r03z_eager_vs_graph.txt);
-        // a host that cannot keep that distance (busy cores, a slow clock) is noticed by do_solve_once and the handle goes over to replay.
+        // a host that cannot keep that distance (busy cores, a slow clock, a profiler; or a graph of 10k poses, whose iteration the device runs in 99 us)
+        // is noticed by do_solve_once and the handle goes over to replay.
         if (getenv("TSGO_FORCE_HOST_SLOW")) host_slow = true;      // test hook
         const bool want_graph = cfg.use_graphs == 1 || (cfg.use_graphs == 2 && (host_slow || !amg_on));      // (block-Jacobi PCG is two short kernels per iteration, thousands of times: always replayed)
         if (want_graph && !collective() && !cg_graph && optimize_calls_on_tables >= 1) { if (int rc = capture_cg_graph()) return rc; }

@@ -149,6 +149,7 @@ constexpr int kYoungLins = 6, kYoungMaxAge = 2;   // ... a graph's first lineari
 constexpr double kHostSlowFraction = 0.6;   // use_graphs = 2: eager launches need the host to be done enqueueing a burst well before the device is done running it.  At 100k
                                             // poses the host needs 0.4 of the solve's time (90 of 217 us per iteration) and eager wins by 2 %; at 10k poses 0.9 (90 of 99 us):
                                             // eager is then as fast on a good run (2.25 ms per step against 2.32) and 20-30 % slower on a bad one — replay
+constexpr int kPaceLead = 1;             // do_solve_paced: iterations the host enqueues ahead of the one whose gate has run
 constexpr int kHierSlack = 2;           // ... and is rebuilt as soon as a solve needs more than this many iterations over its first
 constexpr int kPackedCycleMaxIters = 64; // a multigrid solve that needs more iterations than this is on an ill-conditioned graph: its cycle leaves the packed halves for f32
 constexpr int kHierFreshAbove = 64;     // ... and at every linearisation while solves take more iterations than this (a build costs about four)
@@ -225,6 +226,7 @@ template <typename T> struct Engine : IEngine {
     T *sbuf = nullptr, *tvec = nullptr, *ninv = nullptr, *dl = nullptr, *gpart[2] = {nullptr, nullptr}, *npart = nullptr;
     CgState<T>* st[2] = {nullptr, nullptr};
     CgState<T>* h_state = nullptr;     // pinned
+    int* h_flag = nullptr;             // pinned, coherent: what the gate of the last launched iteration saw (k_iter_gate, do_solve_paced)
     T* h_scratch = nullptr;            // pinned, partial sums
     int nbP = 0, nbL = 0, nbC = 0;
     hipGraphExec_t cg_graph = nullptr;
@@ -300,6 +302,7 @@ template <typename T> struct Engine : IEngine {
         if (cg_graph) { (void)hipGraphExecDestroy(cg_graph); cg_graph = nullptr; }
         for (Slab& sl : slabs) sl.used = 0;
         if (h_state) { (void)hipHostFree(h_state); h_state = nullptr; }
+        if (h_flag) { (void)hipHostFree(h_flag); h_flag = nullptr; }
         if (h_scratch) { (void)hipHostFree(h_scratch); h_scratch = nullptr; }
         if (h_rho) { (void)hipHostFree(h_rho); h_rho = nullptr; }
         have_graph_data = false;
@@ -740,7 +743,7 @@ template <typename T> struct Engine : IEngine {
 
     // solver state a fresh engine starts from: whatever was learnt on the previous graph must not leak into this one
     int reset_solver_state() {
-        have_prev = false; n_prev = 0; n_tested = 0; carried = false; predicted_cg = 0; n_decided = 0; n_slow_seen = 0; n_host_slow = 0; std::fill(iters_by_age, iters_by_age + kAgeSlots, 0); lin_count = 0; n_lins = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
+        have_prev = false; n_prev = 0; n_tested = 0; carried = false; predicted_cg = 0; n_decided = 0; n_slow_seen = 0; n_host_slow = 0; ref_us_per_iter = 0; n_paced_slow = 0; std::fill(iters_by_age, iters_by_age + kAgeSlots, 0); lin_count = 0; n_lins = 0; hier_age = -1; iters_fresh = 0; iters_last = 0;
         const T one = 1;
         { if (int rc_ = copy_sync(one_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
         { if (int rc_ = copy_sync(gscale_dev, &one, sizeof(T), hipMemcpyHostToDevice)) return rc_; }
@@ -917,6 +920,8 @@ template <typename T> struct Engine : IEngine {
         if (int rc = dalloc(&warm_err, (size_t)kMaxWarm * nbC)) return rc;
         if (int rc = dalloc(&warm_order_dev, 1)) return rc;
         HIP_OK(hipHostMalloc((void**)&h_state, sizeof(CgState<T>)));
+        HIP_OK(hipHostMalloc((void**)&h_flag, 16 * sizeof(int), hipHostMallocCoherent));
+        std::memset(h_flag, 0, 16 * sizeof(int));
         HIP_OK(hipHostMalloc((void**)&h_scratch, sizeof(T) * (size_t)(std::max(nbP, 2 * nbC) + nbL + 8)));
         HIP_OK(hipStreamSynchronize(stream));
         lap("state + slot tables to the device");
@@ -1234,10 +1239,11 @@ template <typename T> struct Engine : IEngine {
                            npart, low_cycle && !explicit0 ? zc32 : (float*)nullptr);
     }
     // one PCG iteration reading state slot `slot`, writing slot^1
-    int launch_iteration(int slot) {
+    int launch_iteration(int slot, int seq = 0) {      // seq > 0: the gate reports to the host thread (do_solve_paced)
         if (amg_on) {
             PF(2.0 * nbC * sizeof(T), "stopping rule", "k_iter_gate<%s>", tname());
-            hipLaunchKernelGGL((k_iter_gate<T>), dim3(1), dim3(kBlock), 0, stream, st[slot], (const T*)npart, (const T*)gpart[0], nbC, (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol));
+            hipLaunchKernelGGL((k_iter_gate<T>), dim3(1), dim3(kBlock), 0, stream, st[slot], (const T*)npart, (const T*)gpart[0], nbC, (T)(cfg.pcg_rel_tol * cfg.pcg_rel_tol),
+                               seq > 0 ? h_flag : (int*)nullptr, seq);
             if (int rc = launch_vcycle(slot)) return rc;
             if (int rc = launch_matvec(slot, true)) return rc;
             launch_cg_step(slot);
@@ -1433,8 +1439,53 @@ template <typename T> struct Engine : IEngine {
         }
         return 0;
     }
+    // Eager launches, one device, multigrid cycle: the host thread stays ONE iteration ahead of the device instead of predicting a burst.
+    // The gate (first kernel) of every iteration writes to pinned host memory that it has run and what it saw; the host enqueues
+    // iteration j + 1 when the gate of iteration j has run (90 us of launches against the 217 us the device then spends on j) and
+    // stops at the first gate that reports `done`.  What is wasted past convergence is the rest of that one iteration (29 kernels that
+    // exit at once, 43 us) instead of the two or three a predicted burst over-provisions, an under-provisioned burst (the device idle
+    // while the host enqueues more: 0.4 ms) cannot happen, and the iteration count and failure flag arrive with the report: the stream is
+    // not drained at the end of the solve — the back-substitution queues up behind the last exits (profiles/r03z_paced_eager.txt).
+    double ref_us_per_iter = 0;        // the device's time per iteration as the burst path measured it (the structure's first solves)
+    int n_paced_slow = 0;
+    int do_solve_paced(int* iters, int* fail) {
+        uint64_t* hw = reinterpret_cast<uint64_t*>(h_flag);
+        __atomic_store_n(hw, (uint64_t)0, __ATOMIC_SEQ_CST);
+        static const bool timing = getenv("TSGO_SOLVE_TIMING") != nullptr;
+        const auto w0 = std::chrono::steady_clock::now();
+        auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count(); };
+        int launched = 0; long spins = 0;
+        uint64_t w = 0;
+        for (;;) {
+            w = __atomic_load_n(hw, __ATOMIC_ACQUIRE);      // seq << 32 | done << 31 | fail << 28 | iterations completed (k_iter_gate)
+            const int seen = (int)(w >> 32);
+            if (seen > 0 && ((w >> 31) & 1)) break;
+            if (launched - seen < kPaceLead) {
+                if (launched > cfg.pcg_max_iters + 4) return set_error(-20, "PCG did not terminate");
+                if (int rc = launch_iteration(launched & 1, launched + 1)) return rc;
+                ++launched; spins = 0;
+            } else {
+                __builtin_ia32_pause();
+                if ((spins & 0x3f) == 0x3f) std::this_thread::yield();      // the device needs ~120 us before the next iteration has to be on its way: other threads may have the core
+                if ((++spins & 0xfffff) == 0 && since() > 30e6) return set_error(-20, "PCG: the device stopped reporting (30 s without a gate)");
+            }
+        }
+        *iters = (int)(w & 0x0fffffffu); *fail = (int)((w >> 28) & 7);
+        const double wall = since();
+        if (timing) std::fprintf(stderr, "[tsgo] solve (paced): %d iterations launched, done reported after %d at %.0f us\n", launched, *iters, wall);
+        predicted_cg = *iters;
+        if (amg_on && hier_age >= 0 && hier_age < kAgeSlots) iters_by_age[hier_age] = *fail ? 0 : *iters;
+        // a host that cannot stay ahead shows as iterations that take longer than the burst path measured: then the handle goes over to replay
+        if (cfg.use_graphs == 2 && *iters >= 8 && !*fail && ref_us_per_iter > 0) {
+            if (wall / *iters > 1.3 * ref_us_per_iter) { if (++n_paced_slow >= 3) host_slow = true; } else n_paced_slow = 0;
+        }
+        return 0;
+    }
+    bool paced() const { return amg_on && !cg_graph && !collective() && cfg.use_graphs != 1 && n_decided >= kDecideSolves && !host_slow && !prof_on && h_flag != nullptr; }
+
     // PCG until the device state says done.  The state ring is at slot 0 on entry and on exit.
     int do_solve_once(int* iters, int* fail) {
+        if (paced()) return do_solve_paced(iters, fail);
         int launched = 0;
         const int ch = chunk();
         // chunks before the first look at the device state.  An iteration past convergence costs ~40 us (its kernels exit
@@ -1476,7 +1527,7 @@ template <typename T> struct Engine : IEngine {
         }
         *iters = h_state->iters; *fail = h_state->fail;
         predicted_cg = h_state->iters;
-        if (amg_on && h_state->iters >= 4 && !h_state->fail) dev_us_per_iter = since() / h_state->iters;      // (an upper bound: the solve's wall time over its iterations)
+        if (amg_on && h_state->iters >= 4 && !h_state->fail) { dev_us_per_iter = since() / h_state->iters; if (!cg_graph) ref_us_per_iter = ref_us_per_iter > 0 ? std::min(ref_us_per_iter, dev_us_per_iter) : dev_us_per_iter; }      // (an upper bound: the solve's wall time over its iterations)
         if (amg_on && hier_age >= 0 && hier_age < kAgeSlots) iters_by_age[hier_age] = h_state->fail ? 0 : h_state->iters;
         return 0;
     }

@@ -1454,13 +1454,14 @@ template <typename T> struct Engine : IEngine {
         static const bool timing = getenv("TSGO_SOLVE_TIMING") != nullptr;
         const auto w0 = std::chrono::steady_clock::now();
         auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count(); };
+        static const int pace_lead = getenv("TSGO_PACE_LEAD") ? std::max(1, atoi(getenv("TSGO_PACE_LEAD"))) : kPaceLead;      // research
         int launched = 0; long spins = 0;
         uint64_t w = 0;
         for (;;) {
             w = __atomic_load_n(hw, __ATOMIC_ACQUIRE);      // seq << 32 | done << 31 | fail << 28 | iterations completed (k_iter_gate)
             const int seen = (int)(w >> 32);
             if (seen > 0 && ((w >> 31) & 1)) break;
-            if (launched - seen < kPaceLead) {
+            if (launched - seen < pace_lead) {
                 if (launched > cfg.pcg_max_iters + 4) return set_error(-20, "PCG did not terminate");
                 if (int rc = launch_iteration(launched & 1, launched + 1)) return rc;
                 ++launched; spins = 0;

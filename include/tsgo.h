@@ -63,7 +63,10 @@ typedef struct tsgo_config {
                                 runs it in 217, and eager is 1-3 % faster than the replay — and the replay as soon as it does not (two of a
                                 structure's first three solves whose bursts took more than 0.6 of the solve's own time per iteration to enqueue: no
                                 margin; later only outright starvation, 0.95 three times in a row).  Edge-sharded runs launch eagerly
-                                whatever this says (RCCL calls sit between the kernels).  Same answers, bit for bit. */
+                                whatever this says (RCCL calls sit between the kernels).  Eager launches on one device are PACED: the first kernel of
+                                every iteration reports to pinned host memory, the host thread stays one iteration ahead and stops at the first
+                                report of convergence (no predicted burst, no drain at the end of a solve; it spins, yielding, on that word while
+                                the device works).  Same answers, bit for bit. */
     int32_t rank, world;     /* edge sharding: this process owns shard `rank` of `world` (default 0, 1) */
     int32_t verbose;
     int32_t preconditioner;  /* 1 (default): smoothed-aggregation multigrid V-cycle on the reduced pose system; 0: block-Jacobi on its

@@ -1482,7 +1482,9 @@ template <typename T> struct Engine : IEngine {
         }
         return 0;
     }
-    bool paced() const { return amg_on && !cg_graph && !collective() && cfg.use_graphs != 1 && n_decided >= kDecideSolves && !host_slow && !prof_on && h_flag != nullptr; }
+    // (only where the structure's first solves showed a host with room to spare: on a 150-pose graph an iteration is 20 kernels at the floor, 74 us,
+    // and waiting for a gate before enqueueing the next iteration would expose the host's 60 us every time: use_graphs = 0 keeps the predicted burst there)
+    bool paced() const { return amg_on && !cg_graph && !collective() && cfg.use_graphs != 1 && n_decided >= kDecideSolves && 2 * n_slow_seen <= kDecideSolves && !host_slow && !prof_on && h_flag != nullptr; }
 
     // PCG until the device state says done.  The state ring is at slot 0 on entry and on exit.
     int do_solve_once(int* iters, int* fail) {

@@ -2,7 +2,12 @@
 """bench.py — edges/s per Gauss-Newton iteration on the BASELINE.json workload.
 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--workload c3_100k|c2_10k|c5_1m] [--precision 64]
-  N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+  N > 1, either way: `python bench.py --gpus N ...` starts its own N ranks (a child `python -m torch.distributed.run --nnodes=1
+  --nproc-per-node N --master-addr 127.0.0.1 ...` of this script, started BEFORE this process makes any GPU call; the parent
+  never touches the GPU), or the same command line under an external `torch.distributed.run` (RANK / WORLD_SIZE in the
+  environment): then this process IS a rank.  Every rank runs a watchdog over the phases that can hang on a broken fabric
+  (process group, RCCL communicator, first all-reduce): a phase that does not end within --phase-timeout seconds names itself
+  on stderr and the rank exits 3; the parent kills the whole process group after --launch-timeout and exits non-zero.
 
 A "step" is ONE full Gauss-Newton iteration on the device-resident graph: linearise every edge
 (residual, Jacobian, Huber, block accumulation), solve H delta = b by implicit-Schur PCG to the
@@ -34,7 +39,7 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+# torch is imported by the ranks only (run_rank): the launching parent of a multi-GPU run must not initialise the GPU
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 PMC_TRAFFIC = os.path.join("profiles", "r03_pmc_traffic.json")   # rocprofv3 --pmc digest of this same command (tools/pmc_traffic.py)
@@ -79,37 +84,69 @@ def survey_bytes(P, L, Eo, El, s):
     return b_lin, b_cg, b_upd
 
 
+def host_cpu():
+    """nproc (this process's affinity mask) and the CPU model string, for the cpu_baseline object."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"nproc": len(os.sched_getaffinity(0)), "logical_cpus": os.cpu_count(), "model": model}
+
+
 def cpu_baseline(g, threads):
-    """The SAME graph by the CPU twin (oracle/oracle_sparse.cpp): same layout, same Schur PCG, same tolerance.  kind = "port":
-    the reference's own dense algorithm cannot run this size (O(n^2) memory); what it does at the one
-    configuration it can run (config 1) is timed beside it: reference_dense_c1."""
+    """SURVEY 8d's CPU figures, timed on this host beside the GPU line (rank 0, N = 1 only; ~20-30 s in all):
+    (ii) the SAME graph by the CPU twin (oracle/oracle_sparse.cpp: same layout, same Schur PCG, same tolerance) at all cores
+    (`value`) and at ONE thread — kind = "port": the reference's own dense algorithm cannot run this size (O(n^2) memory);
+    (i) that algorithm itself (dense H, column-pivoted Householder QR, ONE thread: the reference's thread pool is disabled,
+    OptimizerCpu.h:78,125-130) at the only BASELINE configuration it can hold, config 1, in float (remote/app/main.cpp:40) and in
+    double, split into linearise / dense solve / update, with what the 50-iteration request of README.md:15 then costs."""
     from oracle import oracle
     from tests import util
-    oracle.set_threads(threads)
     o = util.to_oracle(g)
-    t0 = time.time()
-    n_it = max(1, ARGS.steps)
-    r = oracle.sparse_optimize(o, n_it, pcg_tol=ARGS.pcg_tol, precond=ARGS.precond)
-    dt = time.time() - t0
-    host = dt - r["seconds_linearize"] - r["seconds_solve"]        # layout + multigrid patterns, built once
-    per_iter = (r["seconds_linearize"] + r["seconds_solve"]) / r["iters"]
-    out = {"value": len(g.e_type) / per_iter, "unit": "edges/s per GN iter", "cores": threads, "kind": "port",
-           "sample": "the first %d GN iterations of the same %s graph by the CPU twin of the same algorithm (%s-preconditioned "
-                     "Schur PCG, tol %g, %.1f PCG iterations per GN iteration): %.1f s of CPU work + %.1f s one-time host setup (excluded, as on the GPU side)"
-                     % (r["iters"], ARGS.workload, ARGS.precond, ARGS.pcg_tol, float(np.mean(r["cg_iters"])), dt - host, host),
-           "pcg_iters_per_gn_iter": float(np.mean(r["cg_iters"])), "seconds_per_gn_iter": per_iter}
-    # the reference's algorithm itself (dense H, column-pivoted Householder QR, float like remote/app/main.cpp:40, ONE thread:
-    # the reference's thread pool is disabled, OptimizerCpu.h:78,125-130) at the only BASELINE configuration it can hold
+    n_edges = len(g.e_type)
+
+    def twin(n_threads, n_it):
+        oracle.set_threads(n_threads)
+        t0 = time.time()
+        r = oracle.sparse_optimize(o, n_it, pcg_tol=ARGS.pcg_tol, precond=ARGS.precond)
+        dt = time.time() - t0
+        work = r["seconds_linearize"] + r["seconds_solve"]
+        return {"cores": n_threads, "gn_iterations": int(r["iters"]), "seconds_per_gn_iter": work / r["iters"], "edges_per_s": n_edges * r["iters"] / work,
+                "pcg_iters_per_gn_iter": float(np.mean(r["cg_iters"])), "seconds_linearize_per_iter": r["seconds_linearize"] / r["iters"],
+                "seconds_solve_per_iter": r["seconds_solve"] / r["iters"], "seconds_host_setup_once": dt - work}
+    big = g.n_poses > 300_000
+    full = twin(threads, 2 if big else min(10, max(2, ARGS.steps)))
+    one = twin(1, 1 if big else 2)
+    out = {"value": full["edges_per_s"], "unit": "edges/s per GN iter", "cores": threads, "kind": "port", "host": host_cpu(),
+           "sample": "the first %d GN iterations of the same %s graph by the CPU twin of the same algorithm (%s-preconditioned Schur PCG, tol %g, "
+                     "%.1f PCG iterations per GN iteration) on %d threads: %.1f s of CPU work + %.1f s one-time host setup (excluded, as on the GPU side); "
+                     "the same twin on ONE thread for %d iteration(s): one_thread"
+                     % (full["gn_iterations"], ARGS.workload, ARGS.precond, ARGS.pcg_tol, full["pcg_iters_per_gn_iter"], threads,
+                        full["seconds_per_gn_iter"] * full["gn_iterations"], full["seconds_host_setup_once"], one["gn_iterations"]),
+           "pcg_iters_per_gn_iter": full["pcg_iters_per_gn_iter"], "seconds_per_gn_iter": full["seconds_per_gn_iter"],
+           "all_cores": full, "one_thread": one}
+    # (i) the reference's algorithm at config 1: 3 iterations per scalar type, phases timed inside the restatement
+    # (oracle_last_phase_seconds) — 50 QR iterations would take 25 s per type, and every iteration is the same dense work.
     oracle.set_threads(1)
-    c1 = util.to_oracle(util.c1_arrays())
-    t0 = time.time()
-    rd = oracle.optimize(c1, 3, mode="cpp", solver="qr", precision="f32")
-    dd = time.time() - t0
-    out["reference_dense_c1"] = {"kind": "reference algorithm, restated (oracle/oracle_dense.cpp); Eigen itself is not in the image",
-                                 "workload": "config 1: 150 poses / 342 landmarks / 2123 edges, n = 1134", "dtype": "f32", "solver": "dense column-pivoted QR",
-                                 "cores": 1, "gn_iterations": int(rd["iters"]), "ms_per_gn_iter": 1e3 * dd / rd["iters"],
-                                 "edges_per_s": len(c1.e_type) * rd["iters"] / dd,
-                                 "note": "dense H is n^2: 39 GB at config 2, 3.9 TB at config 3 — this algorithm cannot run the benchmarked size"}
+    c1g = util.c1_arrays()
+    c1 = util.to_oracle(c1g)
+    dense = {"kind": "reference algorithm, restated (oracle/oracle_dense.cpp); Eigen itself is not in the image",
+             "workload": "config 1: 150 poses / 342 landmarks / 2123 edges, n = 1134", "solver": "dense column-pivoted QR", "cores": 1,
+             "note": "dense H is n^2: 39 GB at config 2, 3.9 TB at config 3 — this algorithm cannot run the benchmarked size"}
+    for prec in ("f32", "f64"):
+        t0 = time.time(); rd = oracle.optimize(c1, 3, mode="cpp", solver="qr", precision=prec); per = (time.time() - t0) / rd["iters"]
+        ph = oracle.last_phase_seconds() / rd["iters"]
+        dense[prec] = {"gn_iterations_timed": int(rd["iters"]), "ms_per_gn_iter": 1e3 * per, "ms_linearize": 1e3 * ph[0], "ms_dense_solve": 1e3 * ph[1],
+                       "ms_update": 1e3 * ph[2], "edges_per_s": len(c1g.e_type) / per,
+                       "seconds_for_the_50_iteration_request": 41 * per,
+                       "seconds_note": "the cpu/eigen rules stop this graph on the plateau rule at iteration 41 (tests/golden/c1_cpprules_ref.npz): 41 x ms_per_gn_iter; 3 iterations timed (the dense solve is the same work every iteration)"}
+    dense["dtype"] = "f32"; dense["gn_iterations"] = dense["f32"]["gn_iterations_timed"]
+    dense["ms_per_gn_iter"] = dense["f32"]["ms_per_gn_iter"]; dense["edges_per_s"] = dense["f32"]["edges_per_s"]
+    out["reference_dense_c1"] = dense
     oracle.set_threads(threads)
     return out
 
@@ -128,22 +165,165 @@ class stdout_to_stderr:
         os.close(self.saved)
 
 
+# ---- multi-GPU launch: this script starts its own ranks, and nothing in it can hang for good -----------------------------------
+PHASE_DIR_ENV = "TSGO_BENCH_PHASE_DIR"
+
+
+class Watch:
+    """A rank's watchdog.  `with watch.phase("rccl communicator")` notes the phase in a file the launching parent reads and, for
+    the phases that can hang on a broken fabric (limit given), arms a timer thread: when the phase has not ended after `limit`
+    seconds the thread names it on stderr and ends the process with os._exit(3) — the main thread may be blocked inside
+    ncclCommInitRank or a collective (both release the GIL), and a process that has touched the GPU is never re-exec'd."""
+
+    def __init__(self, rank):
+        self.rank = rank
+        d = os.environ.get(PHASE_DIR_ENV)
+        self.path = os.path.join(d, "phase.%d" % rank) if d else None
+        self.note("start")
+
+    def note(self, name):
+        self.current = name
+        if self.path:
+            try:
+                with open(self.path + ".tmp", "w") as f:
+                    f.write("%s\n%f\n" % (name, time.time()))
+                os.replace(self.path + ".tmp", self.path)
+            except OSError:
+                pass
+
+    def phase(self, name, limit=None):
+        import contextlib
+        import threading
+
+        @contextlib.contextmanager
+        def cm():
+            self.note(name)
+            timer = None
+            if limit:
+                def fire():
+                    sys.stderr.write("[bench] rank %d: phase '%s' has not ended after %d s — giving up (exit 3)\n" % (self.rank, name, limit))
+                    sys.stderr.flush()
+                    self.note("STUCK in " + name)
+                    os._exit(3)
+                timer = threading.Timer(limit, fire)
+                timer.daemon = True
+                timer.start()
+            try:
+                yield
+            finally:
+                if timer:
+                    timer.cancel()
+        return cm()
+
+
+def launch_ranks():
+    """`python bench.py --gpus N` with no launcher around it: start N ranks as a child `torch.distributed.run` of this same command
+    line, wait for them under a deadline, pass their output through.  This process makes no GPU call (it does not even import
+    torch), so nothing here needs an exec of a process that has initialised the GPU."""
+    import shutil
+    import signal
+    import socket
+    import subprocess
+    import tempfile
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    phase_dir = tempfile.mkdtemp(prefix="tsgo_bench_")
+    env = dict(os.environ)
+    env[PHASE_DIR_ENV] = phase_dir
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: RCCL across processes needs it on this pool
+    env.setdefault("OMP_NUM_THREADS", "2" if ARGS.dry_run_cpu else "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ARGS.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    t0 = time.time()
+    proc = subprocess.Popen(cmd, env=env, start_new_session=True)       # its own process group: one kill reaches every rank
+
+    def phases():
+        out = {}
+        for r in range(ARGS.gpus):
+            try:
+                name, stamp = open(os.path.join(phase_dir, "phase.%d" % r)).read().split("\n")[:2]
+                out[r] = (name, time.time() - float(stamp))
+            except (OSError, ValueError):
+                out[r] = ("not started", time.time() - t0)
+        return out
+
+    rc = None
+    try:
+        while True:
+            try:
+                rc = proc.wait(timeout=1.0)
+                break
+            except subprocess.TimeoutExpired:
+                pass
+            if time.time() - t0 > ARGS.launch_timeout:
+                ph = phases()
+                sys.stderr.write("[bench] %d ranks still running after %d s — killing the process group.  Phases: %s\n"
+                                 % (ARGS.gpus, ARGS.launch_timeout, ", ".join("rank %d: '%s' for %.0f s" % (r, n, a) for r, (n, a) in sorted(ph.items()))))
+                for sig in (signal.SIGTERM, signal.SIGKILL):
+                    try:
+                        os.killpg(proc.pid, sig)
+                    except ProcessLookupError:
+                        break
+                    try:
+                        proc.wait(timeout=10)
+                        break
+                    except subprocess.TimeoutExpired:
+                        continue
+                rc = 4
+                break
+    finally:
+        if rc not in (0, None):
+            ph = phases()
+            sys.stderr.write("[bench] the %d-rank run ended with exit code %s after %.0f s; last phase per rank: %s\n"
+                             % (ARGS.gpus, rc, time.time() - t0, ", ".join("rank %d '%s'" % (r, n) for r, (n, _a) in sorted(ph.items()))))
+        shutil.rmtree(phase_dir, ignore_errors=True)
+    sys.exit(rc if rc is not None else 5)
+
+
+def timed_steps(opt, barrier, n_edges):
+    """W untimed warm-up steps, then exactly K steps between barrier + synchronize on both sides.  One step = one full Gauss-Newton
+    iteration (tsgo_optimize(1)): linearise, solve, update."""
+    chi2, cg = [], []
+    for _ in range(ARGS.warmup):
+        r = opt.optimize(1); chi2 += list(r["chi2"]); cg += list(r["cg_iters"])
+    barrier()
+    t0 = time.perf_counter()
+    ms = {"linearize": 0.0, "solve": 0.0, "update": 0.0}
+    ms_setup, graph_replay = None, False
+    for _ in range(ARGS.steps):
+        r = opt.optimize(1); chi2 += list(r["chi2"]); cg += list(r["cg_iters"])
+        ms["linearize"] += r["ms_linearize"]; ms["solve"] += r["ms_solve"]; ms["update"] += r["ms_update"]; ms_setup = r["ms_setup"]; graph_replay = graph_replay or r["graph_replay"]
+    barrier()
+    dt = time.perf_counter() - t0
+    return {"dt": dt, "chi2": chi2, "cg": cg, "ms": {k: v / ARGS.steps for k, v in ms.items()}, "ms_setup": ms_setup, "graph_replay": graph_replay}
+
+
 def main():
+    if ARGS.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks()                                # never returns
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != ARGS.gpus:
-        if world == 1 and ARGS.gpus > 1:
-            raise SystemExit("--gpus %d needs torch.distributed.run with that many processes" % ARGS.gpus)
+        raise SystemExit("--gpus %d, but the launcher started %d ranks" % (ARGS.gpus, world))
+    watch = Watch(rank)
+    if ARGS.dry_run_cpu:                              # the same spawn path over gloo + the CPU twin (tests/bench_dry_run.py); not a measurement
+        from tests import bench_dry_run
+        return bench_dry_run.run(ARGS, rank, world, watch)
+    import torch
+    n_visible = torch.cuda.device_count()             # (counting devices does not initialise the GPU)
+    if n_visible < world:
+        raise SystemExit("bench.py --gpus %d: %d GPUs needed, %d visible" % (world, world, n_visible))
     from toyslam_amd import synth
     from toyslam_amd.optimizer import HipOptimizer
 
     torch.cuda.set_device(local_rank)
+    dist = None
     if world > 1:
+        import datetime
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        with stdout_to_stderr():
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        with watch.phase("torch.distributed process group (RCCL) + first barrier", ARGS.phase_timeout), stdout_to_stderr():
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank), timeout=datetime.timedelta(seconds=ARGS.phase_timeout))
             dist.barrier()                           # the communicator (and its banner) is created lazily: now
 
     shard = world > 1 and not ARGS.request_parallel
@@ -151,42 +331,49 @@ def main():
     # (tsgo_config.cycle_level0 = 1): one all-reduce per PCG iteration instead of three for 6 % more iterations — ahead as soon as an
     # all-reduce costs more than 19 us (profiles/r02e_explicit_level0_in_cycle.txt).  --implicit-cycle keeps the single-device form.
     explicit_cycle = (shard and not ARGS.implicit_cycle) or ARGS.explicit_cycle
-    g = synth.make_config(ARGS.workload, seed=0 if shard else rank)
+    with watch.phase("synthetic graph"):
+        g = synth.make_config(ARGS.workload, seed=0 if shard else rank)
     n_edges = len(g.e_type)
-    opt = HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol,
-                       rank=rank if shard else 0, world=world if shard else 1,
-                       use_graphs=(False if ARGS.no_graphs else (True if ARGS.graphs else "auto")), lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
-                       preconditioner=ARGS.precond, warm_start=ARGS.warm_start, cycle_level0="explicit" if explicit_cycle else "implicit", cycle_storage=ARGS.cycle_storage)
+
+    def make_opt(rank_, world_, explicit_):
+        return HipOptimizer(device=local_rank, precision=ARGS.precision, pcg_rel_tol=ARGS.pcg_tol, rank=rank_, world=world_,
+                            use_graphs=(False if ARGS.no_graphs else (True if ARGS.graphs else "auto")), lanes_per_pose=ARGS.lanes_pose, lanes_per_lm=ARGS.lanes_lm,
+                            preconditioner=ARGS.precond, warm_start=ARGS.warm_start, cycle_level0="explicit" if explicit_ else "implicit", cycle_storage=ARGS.cycle_storage)
+    opt = make_opt(rank if shard else 0, world if shard else 1, explicit_cycle)
+    rccl_ranks = 1
     if ARGS.force_collective and world == 1:          # research: the sharded code path (eager launches + RCCL calls) with a one-rank communicator
         with stdout_to_stderr():
             opt.comm_init(opt.comm_unique_id())
+            rccl_ranks = opt.comm_selftest()
     if shard:
         with stdout_to_stderr():
             uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
             if rank == 0:
                 uid = torch.tensor(list(opt.comm_unique_id()), dtype=torch.uint8, device="cuda")
-            dist.broadcast(uid, 0)
-            opt.comm_init(bytes(uid.cpu().tolist()))
-    opt.set_graph(g)
+            with watch.phase("broadcast of the RCCL unique id", ARGS.phase_timeout):
+                dist.broadcast(uid, 0)
+                uid_bytes = bytes(uid.cpu().tolist())
+            with watch.phase("engine's RCCL communicator (ncclCommInitRank)", ARGS.phase_timeout):
+                opt.comm_init(uid_bytes)
+            with watch.phase("first all-reduce on the engine's communicator", ARGS.phase_timeout):
+                rccl_ranks = opt.comm_selftest()      # ncclCommCount, and rank + 1 summed over the ranks comes back right
+    with watch.phase("tsgo_set_graph"):
+        opt.set_graph(g)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    chi2, cg = [], []
-    ms_setup = None
-    for _ in range(ARGS.warmup):
-        r = opt.optimize(1); chi2 += list(r["chi2"]); cg += list(r["cg_iters"])
-    barrier()
-    t0 = time.perf_counter()
-    ms_lin = ms_solve = ms_upd = 0.0
-    graph_replay = False
-    for _ in range(ARGS.steps):
-        r = opt.optimize(1); chi2 += list(r["chi2"]); cg += list(r["cg_iters"])
-        ms_lin += r["ms_linearize"]; ms_solve += r["ms_solve"]; ms_upd += r["ms_update"]; ms_setup = r["ms_setup"]; graph_replay = graph_replay or r["graph_replay"]
-    barrier()
-    dt = time.perf_counter() - t0
+    if shard:                                         # the first iteration carries every kind of collective the run will issue
+        with watch.phase("first sharded Gauss-Newton iteration (pose-partial, product and level-0 all-reduces)", ARGS.phase_timeout):
+            opt.optimize(1)
+            opt.set_graph(g)                          # (same structure: values refilled, solver state reset — the timed run starts where an unprobed one would)
+    with watch.phase("warm-up + timed steps", 3 * ARGS.phase_timeout if world > 1 else None):
+        run = timed_steps(opt, barrier, n_edges)
+    dt, chi2, cg = run["dt"], run["chi2"], run["cg"]
+    ms_setup, graph_replay = run["ms_setup"], run["graph_replay"]
+    ms_lin, ms_solve, ms_upd = run["ms"]["linearize"] * ARGS.steps, run["ms"]["solve"] * ARGS.steps, run["ms"]["update"] * ARGS.steps
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,6 +383,25 @@ def main():
             dist.all_reduce(e, op=dist.ReduceOp.SUM)
             n_edges = int(e.item())
     timed_cg = cg[ARGS.warmup:]
+
+    # The other multi-GPU mode beside it, same K / W: every rank its OWN graph of the configuration on its own handle, no data-path
+    # collective (what a multi-GPU graph_optimizer does with independent connections): "request_parallel" in the line.
+    req_par = None
+    if shard and not ARGS.no_request_parallel:
+        with watch.phase("request-parallel leg"):
+            g_own = synth.make_config(ARGS.workload, seed=rank)
+            opt_own = make_opt(0, 1, False)
+            opt_own.set_graph(g_own)
+            run_own = timed_steps(opt_own, barrier, len(g_own.e_type))
+            opt_own.close()
+            t = torch.tensor([run_own["dt"]], dtype=torch.float64, device="cuda"); dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            e = torch.tensor([float(len(g_own.e_type))], dtype=torch.float64, device="cuda"); dist.all_reduce(e, op=dist.ReduceOp.SUM)
+            req_par = {"value": float(e.item()) * ARGS.steps / float(t.item()), "unit": "edges/s", "ms_per_step": 1e3 * float(t.item()) / ARGS.steps, "scaling": "weak",
+                       "pcg_iters_per_gn_iter": float(np.mean(run_own["cg"][ARGS.warmup:])),
+                       "parallelism": "request-parallel: %d independent graphs of the same configuration (seed = rank), one per GPU, no collective" % world}
+            del g_own
+    probes_watch = watch.phase("probes after the timed region (every rank of a sharded run: they contain collectives)", 5 * ARGS.phase_timeout if world > 1 else None)
+    probes_watch.__enter__()
 
     out = None
     # Probes after the timed region.  In a sharded run every probe that linearises or iterates contains collectives, so
@@ -297,6 +503,10 @@ def main():
                                       ("request-parallel: %d independent graphs, one per GPU, no collective" % world if world > 1 else
                                        ("single GPU, collective code path forced (one-rank RCCL communicator)" if ARGS.force_collective else "single GPU")),
                        "hipgraph": graph_replay, "launch_mode": "tsgo_config.use_graphs = %d (%s)" % (0 if ARGS.no_graphs else (1 if ARGS.graphs else 2), "hipGraph replay" if graph_replay else "eager launches")},
+            "rccl_ranks": rccl_ranks,
+            "multi_gpu_design": (("A: landmark-range edge shards, replicated multigrid hierarchy and PCG vectors (DESIGN.md section 5); value = this one graph's edges x K / max-over-ranks time" if shard else
+                                  "request-parallel: one graph per GPU, no collective") if world > 1 else None),
+            "request_parallel": req_par,
             "gn_iters_per_s": ARGS.steps / dt,
             "pcg_iters_per_gn_iter": n_cg,
             "chi2_first_last": [chi2[0], chi2[-1]],
@@ -330,10 +540,13 @@ def main():
             out["iters_to_chi2_tol"] = conv
         if world == 1 and not ARGS.no_cpu:
             out["cpu_baseline"] = cpu_baseline(g, ARGS.cpu_threads or min(16, len(os.sched_getaffinity(0))))
+    probes_watch.__exit__(None, None, None)
     opt.close()
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        with watch.phase("final barrier", ARGS.phase_timeout):
+            dist.barrier()
+            dist.destroy_process_group()
+    watch.note("done")
     if out is not None:
         print(json.dumps(out))
 
@@ -361,6 +574,14 @@ if __name__ == "__main__":
                     help="N = 1: give the engine a one-rank RCCL communicator so that it takes the sharded code path (eager launches, all-reduce calls)")
     ap.add_argument("--no-graphs", dest="no_graphs", action="store_true", help="tsgo_config.use_graphs = 0: eager launches always")
     ap.add_argument("--graphs", dest="graphs", action="store_true", help="tsgo_config.use_graphs = 1: hipGraph replay always (default 2: eager while the host keeps ahead)")
+    ap.add_argument("--no-request-parallel", dest="no_request_parallel", action="store_true",
+                    help="N > 1, sharded: skip the request-parallel leg that is measured beside the sharded one")
+    ap.add_argument("--phase-timeout", dest="phase_timeout", type=int, default=180,
+                    help="seconds a rank's watchdog allows a phase that can hang on a broken fabric (process group, communicator, first all-reduce)")
+    ap.add_argument("--launch-timeout", dest="launch_timeout", type=int, default=1500,
+                    help="N > 1 without a launcher: seconds before the parent kills the ranks it started")
+    ap.add_argument("--dry-run-cpu", dest="dry_run_cpu", action="store_true",
+                    help="rehearsal of the N-rank launch path without GPUs: gloo + the CPU twin (tests/bench_dry_run.py); prints a line marked dry_run, not a measurement")
     ap.add_argument("--no-cpu", dest="no_cpu", action="store_true")
     ap.add_argument("--no-conv", dest="no_conv", action="store_true", help="skip the 50-iteration convergence run")
     ap.add_argument("--cpu-threads", dest="cpu_threads", type=int, default=0)

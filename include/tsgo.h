@@ -178,6 +178,10 @@ int tsgo_solve_step(tsgo_optimizer* opt, double* delta_out, double* chi2_out, in
  * other ranks (any transport); every rank then calls tsgo_comm_init.  Collectives are RCCL. */
 int tsgo_comm_unique_id(uint8_t id_out[128]);
 int tsgo_comm_init(tsgo_optimizer* opt, const uint8_t id[128]);
+/* One element through the all-reduce the solver uses (rank + 1 from every rank, world (world + 1) / 2 expected back) and the
+ * communicator's own rank count (ncclCommCount) in *ranks_out (1 without a communicator).  The first collective is where a
+ * missing peer shows — as a hang: callers run it under a watchdog (bench.py). */
+int tsgo_comm_selftest(tsgo_optimizer* opt, int32_t* ranks_out);
 /* The same sharded path among handles of ONE process (one thread per handle; they may share a device): the all-reduces
  * go through host memory instead of RCCL.  For tests on a box with a single GPU, where RCCL refuses two ranks on one
  * device — it is what lets `world` = 2, 3 run the device kernels' ownership rules there.  The group outlives its handles. */
@@ -214,9 +218,7 @@ typedef struct tsgo_prof_entry {
     char name[64];
     char where[32];
     int32_t launches_per_iteration;
-    int32_t cycle_storage_now;           /* what the multigrid cycle of this structure reads now: 16 (packed halves) or 32 (f32: chosen by
-                                            tsgo_config.cycle_storage, or by the engine after a solve of more than 64 iterations — a graph too
-                                            ill-conditioned for 11-bit blocks); 0 with block-Jacobi */
+    int32_t reserved;                    /* 0 */
     double us, bytes;
 } tsgo_prof_entry;
 int tsgo_profile_iteration(tsgo_optimizer* opt, int32_t reps, tsgo_prof_entry* out, int32_t cap);

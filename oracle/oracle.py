@@ -62,6 +62,7 @@ def lib():
                                                                       f64p, i32p, i32p, f64p]
         L.oracle_solve_f64.argtypes = [f64p, f64p, C.c_int, C.c_int]
         L.oracle_update_pose_f64.argtypes = [f64p, f64p]
+        L.oracle_last_phase_seconds.argtypes = [f64p]; L.oracle_last_phase_seconds.restype = None
         L.oracle_num_unknowns.argtypes = [C.c_int, u32p]
         L.oracle_sparse_step.argtypes = _GRAPH + [C.c_double, C.c_int, C.c_int, C.c_int, C.c_int, ALLREDUCE_FN, C.c_void_p,
                                                   f64p, f64p, i32p]
@@ -151,6 +152,13 @@ def optimize(g, iterations, mode="cpp", solver="chol", lr=0.2, precision="f64"):
     if rc:
         raise RuntimeError("oracle_optimize rc=%d" % rc)
     return dict(v_pos=out, chi2=chi2[:ir[0]].copy(), iters=int(ir[0]), stop=STOP[int(sr[0])], delta_norm=float(dn[0]))
+
+
+def last_phase_seconds():
+    """(linearise, dense solve, vertex update) wall seconds of this thread's last optimize() call."""
+    out = np.zeros(3)
+    lib().oracle_last_phase_seconds(out)
+    return out
 
 
 def solve(H, b, solver="qr"):

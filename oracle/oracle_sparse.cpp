@@ -618,6 +618,9 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
     if (seconds_lin) *seconds_lin = 0;
     if (seconds_solve) *seconds_solve = 0;
     auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec + 1e-9 * ts.tv_nsec; };
+    // research: a PCG tolerance per Gauss-Newton iteration, TSGO_TWIN_TOL_SCHED="1e-7,1e-7,1e-10" (the last entry repeats)
+    std::vector<double> tol_sched;
+    if (const char* e = getenv("TSGO_TWIN_TOL_SCHED")) for (const char* q = e; *q;) { tol_sched.push_back(atof(q)); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
     for (int it = 0; it < iterations; ++it) {
         double t0 = now();
         static const bool cold = getenv("TSGO_TWIN_COLD") != nullptr;
@@ -650,7 +653,8 @@ int oracle_sparse_optimize(GRAPH_ARGS, double* v_pos_out, int iterations, double
         const double err = tw.chi2;
         chi2_trace[it] = err; *iters_run = it + 1;
         if (!py) { if (prevErr > 0 && err > prevErr) { if (++penalty > 2) { *stop_reason = 1; break; } } else penalty = 0; }
-        bool ok; cg_trace[it] = tw.solve_with_fallback(gamma0, pcg_tol, max_cg, &ok);
+        const double tol_it = tol_sched.empty() ? pcg_tol : tol_sched[std::min((size_t)it, tol_sched.size() - 1)];
+        bool ok; cg_trace[it] = tw.solve_with_fallback(gamma0, tol_it, max_cg, &ok);
         if (!ok) { *stop_reason = 4; break; }
         {   // k_save_x: what every order would have made of predicting this delta from the ones before it
             const double a = 1.0 - tw.step;

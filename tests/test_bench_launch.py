@@ -1,0 +1,65 @@
+"""`bench.py --gpus N` started like the N = 1 line (no launcher around it) starts its own ranks, fails loudly without GPUs, and cannot
+hang: every rank's watchdog names the phase it is stuck in, and the parent kills the process group at its deadline.  The same
+spawn path is rehearsed end to end over gloo + the CPU twin (tests/bench_dry_run.py)."""
+import json
+import os
+import subprocess
+import sys
+import time
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def bench(*args, env=None, timeout=240):
+    e = dict(os.environ)
+    e.pop("WORLD_SIZE", None); e.pop("RANK", None); e.pop("LOCAL_RANK", None)
+    e["OMP_WAIT_POLICY"] = "PASSIVE"
+    e.update(env or {})
+    t0 = time.time()
+    p = subprocess.run([sys.executable, BENCH] + list(args), cwd=ROOT, env=e, capture_output=True, text=True, timeout=timeout)
+    return p.returncode, p.stdout, p.stderr, time.time() - t0
+
+
+@pytest.mark.skipif(torch.cuda.device_count() >= 2, reason="needs a box with fewer than 2 GPUs")
+def test_two_gpus_asked_for_on_a_box_without_them_fails_in_seconds_and_says_why():
+    rc, out, err, dt = bench("--gpus", "2", "--steps", "2", "--warmup", "1")
+    assert rc != 0
+    assert "2 GPUs needed, %d visible" % torch.cuda.device_count() in err, err[-2000:]
+    assert out.strip() == ""                      # no JSON line from a run that did not happen
+    assert dt < 90, dt
+
+
+def test_dry_run_of_the_two_rank_launch_path_prints_one_json_line():
+    rc, out, err, _ = bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu")
+    assert rc == 0, err[-3000:]
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["ranks"] == 2 and d["value"] is None and "dry_run" in d
+    assert d["all_reduce_calls"] > 10 and d["chi2_first_last"][1] < d["chi2_first_last"][0]
+
+
+def test_a_rank_that_never_reaches_the_first_all_reduce_is_named_and_the_run_ends_non_zero():
+    rc, out, err, dt = bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu", "--phase-timeout", "5", env={"TSGO_DRY_RUN_STALL_RANK": "1"})
+    assert rc != 0
+    assert "phase 'first all-reduce on the data path' has not ended after 5 s" in err, err[-3000:]
+    assert "STUCK in first all-reduce" in err
+    assert out.strip() == ""
+    assert dt < 120, dt
+
+
+def test_the_parent_kills_its_ranks_at_the_launch_deadline():
+    # the ranks' own watchdogs are set far out: the parent's deadline is what ends this run
+    rc, out, err, dt = bench("--gpus", "2", "--steps", "2", "--warmup", "1", "--dry-run-cpu", "--phase-timeout", "600", "--launch-timeout", "12",
+                             env={"TSGO_DRY_RUN_STALL_RANK": "0"})
+    assert rc == 4, (rc, err[-3000:])
+    assert "killing the process group" in err and "first all-reduce on the data path" in err
+    assert dt < 120, dt
+    # nothing of the run is left behind
+    time.sleep(1.0)
+    left = subprocess.run(["pgrep", "-f", "bench.py --gpus 2 --steps 2 --warmup 1 --dry-run-cpu --phase-timeout 600"], capture_output=True, text=True).stdout.split()
+    assert not left, left

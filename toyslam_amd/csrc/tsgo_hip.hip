@@ -132,6 +132,7 @@ struct IEngine {
     virtual int time_kernel(int which, int reps, double* us, double* bytes) = 0;
     virtual int cycle_probe(int reps, tsgo_cycle_level* out, int cap) = 0;
     virtual int profile_iteration(int reps, tsgo_prof_entry* out, int cap) = 0;
+    virtual int comm_selftest(int* ranks_out) = 0;
     ncclComm_t comm = nullptr;
     tsgo_local_group* lgroup = nullptr;      // in-process stand-in for the communicator (tests on a one-GPU box)
 };
@@ -1298,6 +1299,29 @@ template <typename T> struct Engine : IEngine {
         NCCL_OK(ncclAllReduce(buf, buf, n, sizeof(H) == 8 ? ncclDouble : ncclFloat, ncclSum, comm, stream));
         return 0;
     }
+    // One element through the same all-reduce the solver uses, on the engine's stream: every rank contributes rank + 1 and
+    // must read world (world + 1) / 2 back.  The first collective of a communicator is where a broken fabric or a missing
+    // peer shows (as a hang: bench.py runs this under a watchdog); *ranks_out = what the communicator itself says its size is.
+    int comm_selftest(int* ranks_out) override {
+        HIP_OK(hipSetDevice(cfg.device));
+        int n = 1;
+        if (comm) NCCL_OK(ncclCommCount(comm, &n));
+        else if (lgroup) n = lgroup->world;
+        if (ranks_out) *ranks_out = n;
+        if (!collective()) return 0;
+        T* d = nullptr;
+        HIP_OK(hipMalloc((void**)&d, sizeof(T)));
+        T v = (T)(cfg.rank + 1);
+        int rc = 0;
+        if (hipMemcpyAsync(d, &v, sizeof(T), hipMemcpyHostToDevice, stream) != hipSuccess) rc = set_error(-10, "tsgo_comm_selftest: copy to the device failed");
+        if (!rc) rc = allreduce(d, 1);
+        if (!rc && (hipMemcpyAsync(&v, d, sizeof(T), hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess)) rc = set_error(-10, "tsgo_comm_selftest: the all-reduce did not complete");
+        (void)hipFree(d);
+        if (rc) return rc;
+        const double want = 0.5 * n * (n + 1.0);
+        if (n != std::max(1, cfg.world) || std::fabs((double)v - want) > 1e-6) return set_error(-12, "tsgo_comm_selftest: " + std::to_string(n) + " ranks in the communicator, world " + std::to_string(cfg.world) + ", sum " + std::to_string((double)v) + " instead of " + std::to_string(want));
+        return 0;
+    }
     int capture_cg_graph() {
         hipGraph_t graph = nullptr;
         HIP_OK(hipStreamBeginCapture(stream, hipStreamCaptureModeThreadLocal));
@@ -1943,6 +1967,13 @@ int tsgo_comm_init_local(tsgo_optimizer* o, tsgo_local_group* g) {
     if (o->cfg.world != g->world || o->cfg.rank < 0 || o->cfg.rank >= g->world) return tsgo::set_error(-1, "tsgo_comm_init_local: the handle's rank / world do not fit the group");
     o->eng->lgroup = g;
     return 0;
+}
+int tsgo_comm_selftest(tsgo_optimizer* o, int32_t* ranks_out) {
+    if (!o) return tsgo::set_error(-1, "tsgo_comm_selftest: null argument");
+    int n = 0;
+    const int rc = o->eng->comm_selftest(&n);
+    if (ranks_out) *ranks_out = n;
+    return rc;
 }
 int tsgo_comm_unique_id(uint8_t id_out[128]) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");

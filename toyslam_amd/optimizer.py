@@ -22,7 +22,7 @@ class HipOptimizer:
         cfg = _lib.tsgo_config()
         self.lib.tsgo_default_config(C.byref(cfg))
         cfg.device, cfg.precision, cfg.pcg_rel_tol, cfg.pcg_max_iters = device, precision, pcg_rel_tol, pcg_max_iters
-        cfg.lanes_per_pose, cfg.lanes_per_lm, cfg.use_graphs = lanes_per_pose, lanes_per_lm, (2 if use_graphs == "auto" else int(bool(use_graphs)))
+        cfg.lanes_per_pose, cfg.lanes_per_lm, cfg.use_graphs = lanes_per_pose, lanes_per_lm, self._use_graphs(use_graphs)
         cfg.rank, cfg.world = rank, world
         cfg.preconditioner = {"jacobi": 0, "amg": 1}[preconditioner]
         if xcd_map is not None:
@@ -41,6 +41,17 @@ class HipOptimizer:
         _lib.check(self.lib, self.lib.tsgo_create(C.byref(cfg), C.byref(self.h)), "tsgo_create")
         self.n_vertices = 0
         self._v_in = None
+
+    @staticmethod
+    def _use_graphs(v):
+        """tsgo_config.use_graphs: "auto" / 2 (eager while the host keeps ahead), True / 1 (replay), False / 0 (eager)."""
+        if v == "auto":
+            return 2
+        if isinstance(v, bool):
+            return int(v)
+        if v in (0, 1, 2):
+            return int(v)
+        raise ValueError("use_graphs must be 'auto', True, False, 0, 1 or 2")
 
     def close(self):
         if self.h:
@@ -119,6 +130,12 @@ class HipOptimizer:
     def comm_init(self, uid: bytes):
         buf = (C.c_uint8 * 128).from_buffer_copy(uid)
         _lib.check(self.lib, self.lib.tsgo_comm_init(self.h, buf), "tsgo_comm_init")
+
+    def comm_selftest(self):
+        """One element through the solver's all-reduce; returns the communicator's own rank count (1 without one)."""
+        n = C.c_int32()
+        _lib.check(self.lib, self.lib.tsgo_comm_selftest(self.h, C.byref(n)), "tsgo_comm_selftest")
+        return n.value
 
 
 def local_group(world):

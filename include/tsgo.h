@@ -154,6 +154,11 @@ void tsgo_destroy(tsgo_optimizer* opt);
  * and GraphGpu::ToDevice (remote/cuda/graph/GraphGpu.h:80-187).  Pointers are borrowed for the call. */
 int tsgo_set_graph(tsgo_optimizer* opt, const tsgo_graph* g);
 
+/* tsgo_config.warm_requests only: forget the solver history the handle holds, so that the NEXT tsgo_set_graph starts from nothing —
+ * what a pool of handles calls when a handle goes to another client than the one whose requests built that history (the
+ * reference creates a fresh optimizer per message, remote/app/ConnectionHandler.h:18-21: nothing of one client ever reaches another). */
+void tsgo_reset_history(tsgo_optimizer* opt);
+
 /* Replaces IOptimizer<T>::Optimize(IGraph*) (remote/optimizer/IOptimizer.h:21; loop semantics of
  * OptimizerCpu.h:25-183) including ISolver<T>::Solve (remote/solver/ISolver.h:10).  The graph held by
  * the handle is updated in place. */
@@ -182,14 +187,6 @@ int tsgo_comm_init(tsgo_optimizer* opt, const uint8_t id[128]);
  * communicator's own rank count (ncclCommCount) in *ranks_out (1 without a communicator).  The first collective is where a
  * missing peer shows — as a hang: callers run it under a watchdog (bench.py). */
 int tsgo_comm_selftest(tsgo_optimizer* opt, int32_t* ranks_out);
-/* The same sharded path among handles of ONE process (one thread per handle; they may share a device): the all-reduces
- * go through host memory instead of RCCL.  For tests on a box with a single GPU, where RCCL refuses two ranks on one
- * device — it is what lets `world` = 2, 3 run the device kernels' ownership rules there.  The group outlives its handles. */
-typedef struct tsgo_local_group tsgo_local_group;
-int tsgo_local_group_create(int32_t world, tsgo_local_group** out);
-void tsgo_local_group_destroy(tsgo_local_group* group);
-int tsgo_comm_init_local(tsgo_optimizer* opt, tsgo_local_group* group);
-
 /* Timing probe used by bench.py: average device time (hipEvent, microseconds) of `reps` back-to-back
  * launches of one kernel on the handle's stream, and the algorithmic bytes one launch moves.
  * which: 0 schur_lm, 1 schur_pose, 2 cg_update, 3 lin_lm, 4 lin_pose, 5 one whole PCG iteration

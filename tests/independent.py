@@ -9,6 +9,10 @@ the restatement of remote/graph/edge/EdgeSe2Point2d.h:27-70 and EdgeSe2.h:23-38,
   H @ delta, matrix-free                      J^T (Omega_w (J delta)) + gauge, edge by edge
 
 so that a device linearisation and a device solve can be checked at 100k and 1M poses:  ||H delta - b|| / ||b||.
+
+Round 4: the UPDATE and the STOP RULES too (apply_update, GnRules), so that a multi-iteration trajectory at 100k poses can be followed
+step by step without the twin: vertices after an iteration = the reference's own update rule applied to the device's delta, and the
+loop's decisions = the reference's rules evaluated on the checker's own chi^2 and ||delta||.
 """
 import numpy as np
 
@@ -87,3 +91,55 @@ class Linearisation:
         r = self.apply_H(delta) - b
         mask = np.arange(3)[None, :] < self.dims[:, None]
         return float(np.linalg.norm(r[mask]) / np.linalg.norm(b[mask]))
+
+
+STEP = 0.2                 # remote/optimizer/OptimizerCpu.h:164
+PLATEAU_TOL = 1e-3         # :167
+DELTA_TOL = 1e-3           # :173
+
+
+def apply_update(v_pos, v_type, delta, step=STEP):
+    """The reference's vertex update with the loop's fixed step (OptimizerCpu.h:159-165):
+    VertexSe2::Update (remote/graph/vertex/VertexSe2.h:16-27): theta <- atan2(R10, R00) + step * d_theta, translation added in the
+    WORLD frame (no R * d); Vertex2d::Update (vertex/Vertex2d.h:16-19): p <- p + step * d.  (x, y, theta) in and out."""
+    out = np.array(v_pos, dtype=np.float64, copy=True)
+    pose = v_type == 0
+    th = np.arctan2(np.sin(out[pose, 2]), np.cos(out[pose, 2])) + step * delta[pose, 2]
+    out[pose, 0] += step * delta[pose, 0]; out[pose, 1] += step * delta[pose, 1]
+    out[pose, 2] = np.arctan2(np.sin(th), np.cos(th))              # what a read-out of the rotation block gives (SerializeGraphFuncCpu.h:28)
+    lm = ~pose
+    out[lm, 0] += step * delta[lm, 0]; out[lm, 1] += step * delta[lm, 1]
+    return out
+
+
+def delta_norm(delta, v_type):
+    """||delta||_2 over the unknowns (3 per pose, 2 per landmark), unscaled (OptimizerCpu.h:173)."""
+    mask = np.arange(3)[None, :] < np.where(v_type == 0, 3, 2)[:, None]
+    return float(np.sqrt((delta[mask] ** 2).sum()))
+
+
+class GnRules:
+    """The loop rules of OptimizerCpu.h:140-153,167-179, fed one iteration at a time with the checker's own numbers:
+    before_solve(chi2) -> "worse" or None (penalty > 2 on rising chi^2: break BEFORE the solve);
+    after_update(chi2, norm) -> "plateau" / "converged" / None (plateau first, then the short step)."""
+
+    def __init__(self):
+        self.prev = -1.0
+        self.penalty = 0
+
+    def before_solve(self, chi2):
+        if self.prev > 0 and chi2 > self.prev:
+            self.penalty += 1
+            if self.penalty > 2:
+                return "worse"
+        else:
+            self.penalty = 0
+        return None
+
+    def after_update(self, chi2, norm):
+        if abs(chi2 - self.prev) < PLATEAU_TOL:
+            return "plateau"
+        if norm < DELTA_TOL:
+            return "converged"
+        self.prev = chi2
+        return None

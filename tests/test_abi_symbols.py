@@ -10,8 +10,8 @@ from toyslam_amd import _lib, build
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "tsgo.h")).read()
+def declared_symbols(header="tsgo.h"):
+    text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     return sorted(set(re.findall(r"\b(tsgo_[a-z_0-9]+)\s*\(", text)))
 
@@ -35,6 +35,32 @@ def test_hip_library_exports_every_symbol():
     lib = C.CDLL(build.HIP_SO)
     for s in declared_symbols():
         assert hasattr(lib, s), s
+
+
+def test_testing_library_exports_the_product_abi_plus_the_testing_entry_points():
+    if not os.path.exists(build.HIP_TESTING_SO):
+        pytest.skip("libtsgo_hip_testing.so not built yet (run __graft_entry__.build())")
+    lib = C.CDLL(build.HIP_TESTING_SO)
+    for s in declared_symbols() + declared_symbols("tsgo_testing.h"):
+        assert hasattr(lib, s), s
+    assert sorted(declared_symbols("tsgo_testing.h")) == sorted(_lib.TESTING_SYMBOLS)
+
+
+def test_shipped_binaries_contain_no_test_hook_or_research_variable():
+    """`strings graph_optimizer | grep TSGO_INJECT` is empty — and so is every other name of host/knobs.h's
+    research set, in the server and in both product libraries; the testing twin of the library has them."""
+    names = [b"TSGO_INJECT_AMG_FAILURE", b"TSGO_FORCE_HOST_SLOW", b"TSGO_FORCE_PACED", b"TSGO_SYM_DECLINE", b"TSGO_HOST_PRODUCTS", b"TSGO_HIER_MAX_AGE",
+             b"TSGO_HIER_SLACK", b"TSGO_AGGC", b"TSGO_AGG_LIST", b"TSGO_AGG_MODE", b"TSGO_SWEEPS_LIST", b"TSGO_PACE_LEAD", b"TSGO_SORT_WINDOW_POSE", b"tsgo_local_group_create"]
+    for path in (build.HIP_SO, build.HOST_SO, build.SERVER):
+        if not os.path.exists(path):
+            pytest.skip("%s not built yet" % path)
+        blob = open(path, "rb").read()
+        for n in names:
+            assert n not in blob, (path, n)
+    if os.path.exists(build.HIP_TESTING_SO):
+        blob = open(build.HIP_TESTING_SO, "rb").read()
+        for n in names:
+            assert n in blob, n
 
 
 def test_device_entry_points_fail_loudly_without_a_gpu():

@@ -121,3 +121,108 @@ def test_c3_twelve_iterations_final_chi2_and_poses():
     gf = g.copy(); gf.v_pos[:] = v
     chi_np = independent.Linearisation(gf).chi2
     assert abs(chi_dev - chi_np) <= 1e-9 * chi_np
+
+
+def _follow_step_by_step(name, n_iterations, step_fn, vertices_fn, optimize_fn):
+    """VERDICT r03 item 6.  Each of `n_iterations` Gauss-Newton iterations of the device is checked by tests/independent.py alone
+    (no product code, no twin): the device's state before the iteration is re-linearised in numpy (chi^2), the device's delta must
+    solve THAT system (||H delta - b|| / ||b||), the reference's own update rule applied to the delta must give the device's next
+    state, and the device's ||delta|| and stop decision must be the ones the reference's rules give on the checker's numbers."""
+    g = synth.make_config(name)
+    cur = g.copy()
+    for it in range(n_iterations):
+        rules = independent.GnRules()                      # the loop state (prevErr, penalty) lives for ONE tsgo_optimize call, as in OptimizerCpu.h:76-80
+        lin = independent.Linearisation(cur)
+        step = step_fn()                                   # the device's delta at this state (state untouched)
+        assert abs(step["chi2"] - lin.chi2) <= 1e-11 * lin.chi2, (it, step["chi2"], lin.chi2)
+        assert lin.residual_of(step["delta"]) < 1e-9
+        assert rules.before_solve(lin.chi2) is None
+        r = optimize_fn()                                  # the same iteration for real: linearise, solve, update
+        assert r["iters"] == 1 and abs(r["chi2"][0] - lin.chi2) <= 1e-11 * lin.chi2
+        v_next = independent.apply_update(cur.v_pos, g.v_type, step["delta"])
+        v_dev = vertices_fn()
+        assert util.max_vertex_diff(v_dev, v_next, g.v_type) < 1e-9, (it, util.max_vertex_diff(v_dev, v_next, g.v_type))
+        norm = independent.delta_norm(step["delta"], g.v_type)
+        assert abs(r["delta_norm"] - norm) <= 1e-8 * norm, (r["delta_norm"], norm)
+        verdict = rules.after_update(lin.chi2, norm)
+        assert r["stop"] == {None: "cap", "plateau": "plateau", "converged": "converged"}[verdict]      # (one iteration per call: the first call has nothing to plateau against)
+        cur = cur.copy(); cur.v_pos[:] = v_dev
+    return g
+
+
+def test_c3_three_iterations_followed_step_by_step_by_the_numpy_checker():
+    o = HipOptimizer(pcg_rel_tol=1e-12)
+    try:
+        state = {}
+
+        def first_use():
+            if "g" not in state:
+                state["g"] = synth.make_config("c3_100k"); o.set_graph(state["g"])
+        def step_fn():
+            first_use(); return o.solve_step()
+        _follow_step_by_step("c3_100k", 3, step_fn, o.vertices, lambda: o.optimize(1))
+    finally:
+        o.close()
+
+
+def test_c3_two_sharded_iterations_followed_step_by_step_by_the_numpy_checker():
+    """The same through the edge-sharded device path: two in-process ranks (TSGO_TESTING library: the in-process all-reduce group),
+    every call made by both ranks' threads; poses are replicated, each rank returns its own landmarks."""
+    import threading
+    from toyslam_amd.optimizer import free_local_group, local_group
+    world = 2
+    g = synth.make_config("c3_100k")
+    group = local_group(world)
+    hs = [HipOptimizer(rank=k, world=world, pcg_rel_tol=1e-12, testing=True) for k in range(world)]
+
+    def on_all(fn):
+        out, errs = [None] * world, []
+
+        def main(k):
+            try:
+                out[k] = fn(hs[k])
+            except Exception as e:      # noqa: BLE001
+                errs.append((k, repr(e)))
+        th = [threading.Thread(target=main, args=(k,), daemon=True) for k in range(world)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=600)
+        assert not errs, errs
+        assert not any(t.is_alive() for t in th), "a rank is stuck in the in-process all-reduce"
+        return out
+
+    def merged(per_rank, base):
+        """poses from rank 0; landmark rows from the rank that owns them (the others leave `base` untouched)"""
+        v = per_rank[0].copy()
+        for vr in per_rank[1:]:
+            m = np.any(vr != base, axis=1) & (g.v_type == 1)
+            v[m] = vr[m]
+        return v
+    try:
+        on_all(lambda o: o.comm_init_local(group))
+        on_all(lambda o: o.set_graph(g))
+        state = {"v": g.v_pos.copy()}
+
+        def step_fn():
+            outs = on_all(lambda o: o.solve_step())
+            d = outs[0]["delta"].copy()
+            for s in outs[1:]:                          # a rank's landmark deltas are its own; zero elsewhere
+                m = np.any(s["delta"] != 0, axis=1) & (g.v_type == 1)
+                d[m] = s["delta"][m]
+            assert all(s["chi2"] == outs[0]["chi2"] and s["cg_iters"] == outs[0]["cg_iters"] for s in outs)      # ranks agree bit for bit
+            return dict(delta=d, chi2=outs[0]["chi2"], cg_iters=outs[0]["cg_iters"])
+
+        def vertices_fn():
+            state["v"] = merged(on_all(lambda o: o.vertices()), g.v_pos)
+            return state["v"]
+
+        def optimize_fn():
+            outs = on_all(lambda o: o.optimize(1))
+            assert all(r["chi2"][0] == outs[0]["chi2"][0] and r["stop"] == outs[0]["stop"] for r in outs)
+            return outs[0]
+        _follow_step_by_step("c3_100k", 2, step_fn, vertices_fn, optimize_fn)
+    finally:
+        for o in hs:
+            o.close()
+        free_local_group(group)

@@ -101,7 +101,7 @@ def test_hipgraph_replay_equals_eager_launches(precond, monkeypatch):
             monkeypatch.setenv("TSGO_FORCE_HOST_SLOW", "1")
         else:
             monkeypatch.delenv("TSGO_FORCE_HOST_SLOW", raising=False)
-        o = HipOptimizer(pcg_rel_tol=1e-10, use_graphs=use_graphs, preconditioner=precond)
+        o = HipOptimizer(pcg_rel_tol=1e-10, use_graphs=use_graphs, preconditioner=precond, testing=slow)      # the hook lives in the TSGO_TESTING build only
         try:
             o.set_graph(g)
             o.optimize(1)                   # the first call on new tables launches eagerly either way; the graph is captured at the second
@@ -151,7 +151,7 @@ def test_warm_start_and_lagged_hierarchy_change_the_work_not_the_answer(monkeypa
             monkeypatch.delenv("TSGO_HIER_MAX_AGE", raising=False)
         else:
             monkeypatch.setenv("TSGO_HIER_MAX_AGE", max_age)
-        o = HipOptimizer(pcg_rel_tol=1e-12, warm_start=warm)
+        o = HipOptimizer(pcg_rel_tol=1e-12, warm_start=warm, testing=max_age is not None)      # TSGO_HIER_MAX_AGE is a research variable: TSGO_TESTING build
         try:
             o.set_graph(g); r = o.optimize(14); runs[name] = (r, o.vertices())
         finally:
@@ -237,7 +237,7 @@ def test_solver_history_survives_set_graph_when_asked_to(world):
         """`requests`: functions (previous (graph, vertices) or None) -> graph, sent one after the other to ONE handle per rank;
         returns [(result of rank 0, vertices merged over the ranks, graph, results of all ranks)] per request"""
         group = local_group(world) if world > 1 else None
-        hs = [HipOptimizer(pcg_rel_tol=1e-12, rank=k, world=world, warm_requests=warm) for k in range(world)]
+        hs = [HipOptimizer(pcg_rel_tol=1e-12, rank=k, world=world, warm_requests=warm, testing=world > 1) for k in range(world)]
         res = []; prev = None
         try:
             if world > 1:
@@ -567,7 +567,7 @@ def test_pair_lists_built_on_the_device_equal_the_hosts(monkeypatch, n_poses, lc
             monkeypatch.setenv("TSGO_HOST_PRODUCTS", "1")
         else:
             monkeypatch.delenv("TSGO_HOST_PRODUCTS", raising=False)
-        o = HipOptimizer(pcg_rel_tol=1e-12)
+        o = HipOptimizer(pcg_rel_tol=1e-12, testing=host)      # the host builder is forced in the TSGO_TESTING build; the device builder runs in the PRODUCT library
         try:
             o.set_graph(g); res[host] = (o.optimize(5), o.vertices())
         finally:
@@ -587,7 +587,7 @@ def test_device_pattern_builders_hand_back_to_the_host(monkeypatch, bits):
     res = []
     for decline in (0, bits):
         monkeypatch.setenv("TSGO_SYM_DECLINE", str(decline))
-        o = HipOptimizer(pcg_rel_tol=1e-12)
+        o = HipOptimizer(pcg_rel_tol=1e-12, testing=decline != 0)      # (the product library does not know the variable)
         try:
             o.set_graph(g); res.append((o.optimize(4), o.vertices()))
         finally:
@@ -662,7 +662,7 @@ def test_aggregates_of_four_on_every_level_still_give_the_same_answer(monkeypatc
     finally:
         o.close()
     monkeypatch.setenv("TSGO_AGGC", "4")
-    o = HipOptimizer(pcg_rel_tol=1e-10, preconditioner="amg")
+    o = HipOptimizer(pcg_rel_tol=1e-10, preconditioner="amg", testing=True)
     try:
         o.set_graph(g); r = o.optimize(2); v = o.vertices()
     finally:
@@ -728,7 +728,7 @@ def test_block_jacobi_repeat_of_a_failed_multigrid_solve(monkeypatch):
     for inject in (False, True):
         if inject:
             monkeypatch.setenv("TSGO_INJECT_AMG_FAILURE", "1")
-        o = HipOptimizer(pcg_rel_tol=1e-12)
+        o = HipOptimizer(pcg_rel_tol=1e-12, testing=inject)
         try:
             o.set_graph(g); res[inject] = (o.optimize(4), o.vertices())
         finally:
@@ -738,6 +738,80 @@ def test_block_jacobi_repeat_of_a_failed_multigrid_solve(monkeypatch):
     assert r1["cg_iters"][0] > 5 * r0["cg_iters"][0]                 # the first solve ran block-Jacobi
     np.testing.assert_allclose(r1["chi2"], r0["chi2"], rtol=1e-10)
     assert util.max_vertex_diff(v1, v0, g.v_type) < 1e-8
+
+
+def test_the_shipped_library_ignores_test_hooks_and_research_variables(monkeypatch):
+    """a production process must not change its numerics, or declare a solver failure, because of an inherited
+    environment.  The hooks exist in libtsgo_hip_testing.so only: with all of them set, the product library answers bit for bit
+    what it answers without them (and its binary does not contain their names: tests/test_abi_symbols.py)."""
+    g = synth.make(3000, 10, loop_closures=20, seed=3)
+    res = []
+    for hooks in (False, True):
+        for name in ("TSGO_INJECT_AMG_FAILURE", "TSGO_FORCE_HOST_SLOW", "TSGO_FORCE_PACED", "TSGO_SYM_DECLINE", "TSGO_HOST_PRODUCTS", "TSGO_AGGC", "TSGO_HIER_MAX_AGE", "TSGO_SWEEPS_LIST"):
+            if hooks:
+                monkeypatch.setenv(name, "1")
+            else:
+                monkeypatch.delenv(name, raising=False)
+        o = HipOptimizer(pcg_rel_tol=1e-12)
+        try:
+            o.set_graph(g); res.append((o.optimize(4), o.vertices()))
+        finally:
+            o.close()
+    assert res[1][0]["fallbacks"] == 0 and not res[1][0]["graph_replay"]
+    np.testing.assert_array_equal(res[0][0]["chi2"], res[1][0]["chi2"])
+    np.testing.assert_array_equal(res[0][0]["cg_iters"], res[1][0]["cg_iters"])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+
+
+def test_paced_eager_launches_give_the_same_bits_as_bursts_and_replay(monkeypatch):
+    """do_solve_paced (the host thread one iteration ahead of the device, paced by the gate kernel's reports) is entered
+    only after timing heuristics, so nothing pinned it.  TSGO_FORCE_PACED (TSGO_TESTING build) takes it from the first solve on:
+    same bits as eager bursts and as hipGraph replay — through a warm start that already meets the tolerance (0 iterations, at a
+    loose tolerance), and through an injected
+    multigrid failure whose block-Jacobi repeat runs right after a paced solve (stale gate reports must not end it)."""
+    g = synth.make(2500, 10, loop_closures=10, seed=17)
+
+    def run(paced, inject, lead=None, use_graphs=0, tol=1e-10):
+        for name, on in (("TSGO_FORCE_PACED", paced), ("TSGO_INJECT_AMG_FAILURE", inject)):
+            if on:
+                monkeypatch.setenv(name, "1")
+            else:
+                monkeypatch.delenv(name, raising=False)
+        if lead:
+            monkeypatch.setenv("TSGO_PACE_LEAD", str(lead))
+        else:
+            monkeypatch.delenv("TSGO_PACE_LEAD", raising=False)
+        o = HipOptimizer(pcg_rel_tol=tol, use_graphs=use_graphs, testing=True)
+        try:
+            o.set_graph(g)
+            a = o.optimize(4)
+            b = o.optimize(30)
+            return a, b, o.vertices()
+        finally:
+            o.close()
+    base = run(False, False)
+    for paced, inject, lead, ug in ((True, False, None, 0), (True, False, 3, 0), (False, False, None, 1)):
+        r = run(paced, inject, lead, ug)
+        for k in (0, 1):
+            np.testing.assert_array_equal(r[k]["chi2"], base[k]["chi2"])
+            np.testing.assert_array_equal(r[k]["cg_iters"], base[k]["cg_iters"])
+            assert r[k]["stop"] == base[k]["stop"]
+        np.testing.assert_array_equal(r[2], base[2])
+    # a warm start that already meets the rule (k_warm_scale sets `done`: the first gate reports a finished solve of 0 iterations): at a
+    # loose tolerance the extrapolated delta is good enough by itself
+    loose_burst, loose_paced = run(False, False, tol=3e-2), run(True, False, 2, tol=3e-2)
+    assert loose_burst[1]["cg_iters"].min() == 0, loose_burst[1]["cg_iters"]
+    for k in (0, 1):
+        np.testing.assert_array_equal(loose_paced[k]["chi2"], loose_burst[k]["chi2"])
+        np.testing.assert_array_equal(loose_paced[k]["cg_iters"], loose_burst[k]["cg_iters"])
+    np.testing.assert_array_equal(loose_paced[2], loose_burst[2])
+    inj_burst, inj_paced = run(False, True), run(True, True, 3)
+    assert inj_paced[0]["fallbacks"] == 1 and inj_burst[0]["fallbacks"] == 1
+    for k in (0, 1):
+        np.testing.assert_array_equal(inj_paced[k]["chi2"], inj_burst[k]["chi2"])
+        np.testing.assert_array_equal(inj_paced[k]["cg_iters"], inj_burst[k]["cg_iters"])
+    np.testing.assert_array_equal(inj_paced[2], inj_burst[2])
+    np.testing.assert_allclose(inj_paced[1]["chi2"][-1], base[1]["chi2"][-1], rtol=1e-9)
 
 
 def test_vertex_and_edge_order_do_not_matter_on_the_device(opt):

@@ -22,7 +22,7 @@ def _run_sharded(g, world, iterations, **kw):
 
     def rank_main(rank):
         try:
-            o = HipOptimizer(rank=rank, world=world, **kw)
+            o = HipOptimizer(rank=rank, world=world, testing=True, **kw)
             try:
                 o.comm_init_local(group)
                 o.set_graph(g)
@@ -104,7 +104,7 @@ def test_bench_probe_sequence_of_a_sharded_run_does_not_deadlock():
 
     def rank_main(rank):
         try:
-            o = HipOptimizer(rank=rank, world=world, pcg_rel_tol=1e-10)
+            o = HipOptimizer(rank=rank, world=world, pcg_rel_tol=1e-10, testing=True)
             try:
                 o.comm_init_local(group)
                 o.set_graph(g)

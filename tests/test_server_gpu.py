@@ -213,6 +213,37 @@ def test_a_connections_next_request_continues_from_the_solver_history_of_its_las
     print("PCG iterations per request (first / same structure again / grown): warm_requests on %s, off %s" % (counts["1"], counts["0"]))
 
 
+def test_solver_history_never_crosses_from_one_connection_to_another():
+    """engine handles are pooled across connections, and SLAM clients all number their vertices 0..N — a handle given to
+    another connection must not start that client's solves from the previous client's deltas.  ONE engine (ENGINES = 1), two clients
+    sending the same structure: the server's log line says per request whether it started from carried history."""
+    import re
+    from toyslam_amd import synth
+    from toyslam_amd.graph import GraphArrays
+    g0 = synth.make(2500, 8, seed=29).rounded_to_wire()
+    port, proc = _start(6, "64", "1e-10", "0", "1", "cpp", "constant", "1")
+    try:
+        with socket.create_connection(("127.0.0.1", port)) as a, socket.create_connection(("127.0.0.1", port)) as b:
+            va0 = remote.bytes_to_vertices(_roundtrip(a, remote.graph_to_bytes(g0)), g0)
+            g1 = GraphArrays(g0.v_id, g0.v_type, va0, g0.e_type, g0.e_ids, g0.e_meas, g0.e_inf, g0.fixed)
+            va1 = remote.bytes_to_vertices(_roundtrip(a, remote.graph_to_bytes(g1)), g1)          # A again: its own history
+            vb0 = remote.bytes_to_vertices(_roundtrip(b, remote.graph_to_bytes(g1)), g1)          # B's first request, same structure, same handle
+            vb1 = remote.bytes_to_vertices(_roundtrip(b, remote.graph_to_bytes(g1)), g1)          # B again: nothing to continue (same input: no step taken in between)
+            va2 = remote.bytes_to_vertices(_roundtrip(a, remote.graph_to_bytes(g1)), g1)          # A after B used the handle: forgotten
+    finally:
+        _stop(proc)
+    out = proc.stdout.read()
+    hist = [int(m) for m in re.findall(r"history=(\d+)", out)][-5:]
+    assert len(hist) == 5, out[-2000:]
+    assert hist[0] == 0 and hist[1] in (1, 2), hist       # A: first request cold, second one from its own history
+    assert hist[2] == 0, hist                              # B's first request on the handle A just used: cold
+    assert hist[4] == 0, hist                              # A, after the handle served B: cold again
+    # B's answer is what a connection of its own server would have got: the same request, cold, is deterministic
+    assert np.array_equal(vb0, va2), np.abs(vb0 - va2).max()
+    assert util.max_vertex_diff(va1, vb0, g1.v_type) < 2e-6       # warm or cold: the same answer to the solver's tolerance (f32 on the wire)
+    assert vb1.shape == vb0.shape
+
+
 def test_trailing_arguments_select_the_python_rules_and_the_analytic_odometry_jacobians():
     """The server's optional trailing arguments (after the reference's five): PRECISION PCG_TOL DEVICE ENGINES RULES ODOM_JACOBIAN.
     `python:0.5 analytic` must give what the in-process handle gives with rules="python", lr=0.5, odom_jacobian="analytic" —

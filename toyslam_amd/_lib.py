@@ -55,8 +55,9 @@ class tsgo_amg_info(C.Structure):
 HOST_SYMBOLS = ["tsgo_default_config", "tsgo_last_error", "tsgo_wire_decode", "tsgo_wire_new", "tsgo_wire_decode_into", "tsgo_wire_view", "tsgo_wire_free",
                 "tsgo_wire_encode_response", "tsgo_wire_encode_request", "tsgo_synth_create", "tsgo_synth_view",
                 "tsgo_synth_truth", "tsgo_synth_free", "tsgo_layout_probe", "tsgo_amg_probe", "tsgo_amg_probe_shard"]
-DEVICE_SYMBOLS = ["tsgo_create", "tsgo_destroy", "tsgo_set_graph", "tsgo_optimize", "tsgo_get_vertices",
-                  "tsgo_linearize", "tsgo_solve_step", "tsgo_comm_unique_id", "tsgo_comm_init", "tsgo_comm_selftest", "tsgo_time_kernel", "tsgo_cycle_probe", "tsgo_profile_iteration", "tsgo_local_group_create", "tsgo_local_group_destroy", "tsgo_comm_init_local"]
+DEVICE_SYMBOLS = ["tsgo_create", "tsgo_destroy", "tsgo_set_graph", "tsgo_reset_history", "tsgo_optimize", "tsgo_get_vertices",
+                  "tsgo_linearize", "tsgo_solve_step", "tsgo_comm_unique_id", "tsgo_comm_init", "tsgo_comm_selftest", "tsgo_time_kernel", "tsgo_cycle_probe", "tsgo_profile_iteration"]
+TESTING_SYMBOLS = ["tsgo_local_group_create", "tsgo_local_group_destroy", "tsgo_comm_init_local"]      # include/tsgo_testing.h: libtsgo_hip_testing.so only
 
 
 def _declare_host(L):
@@ -87,6 +88,7 @@ def _declare_device(L):
     L.tsgo_destroy.argtypes = [vp]; L.tsgo_destroy.restype = None
     L.tsgo_set_graph.argtypes = [vp, C.POINTER(tsgo_graph)]
     L.tsgo_optimize.argtypes = [vp, C.c_int32, C.POINTER(tsgo_stats)]
+    L.tsgo_reset_history.argtypes = [vp]; L.tsgo_reset_history.restype = None
     L.tsgo_get_vertices.argtypes = [vp, vp]
     L.tsgo_linearize.argtypes = [vp, vp, vp, C.POINTER(C.c_double)]
     L.tsgo_solve_step.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(C.c_int32)]
@@ -96,6 +98,10 @@ def _declare_device(L):
     L.tsgo_time_kernel.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tsgo_cycle_probe.argtypes = [vp, C.c_int32, C.POINTER(tsgo_cycle_level), C.c_int32]
     L.tsgo_profile_iteration.argtypes = [vp, C.c_int32, C.POINTER(tsgo_prof_entry), C.c_int32]
+
+
+def _declare_testing(L):
+    vp = C.c_void_p
     L.tsgo_local_group_create.argtypes = [C.c_int32, C.POINTER(vp)]
     L.tsgo_local_group_destroy.argtypes = [vp]; L.tsgo_local_group_destroy.restype = None
     L.tsgo_comm_init_local.argtypes = [vp, vp]
@@ -103,6 +109,7 @@ def _declare_device(L):
 
 _host = None
 _hip = None
+_hip_testing = None
 
 
 def host_lib():
@@ -127,6 +134,20 @@ def hip_lib():
         _declare_host(_hip)
         _declare_device(_hip)
     return _hip
+
+
+def hip_testing_lib():
+    """libtsgo_hip_testing.so: the same sources built with -DTSGO_TESTING — test hooks, research variables and the in-process
+    all-reduce group (include/tsgo_testing.h).  Loaded by the tests that need one of those; never by the product path."""
+    global _hip_testing
+    if _hip_testing is None:
+        if not os.path.exists(build.HIP_TESTING_SO):
+            raise RuntimeError("toyslam_amd: %s is missing — run __graft_entry__.build()" % build.HIP_TESTING_SO)
+        _hip_testing = C.CDLL(build.HIP_TESTING_SO)
+        _declare_host(_hip_testing)
+        _declare_device(_hip_testing)
+        _declare_testing(_hip_testing)
+    return _hip_testing
 
 
 def check(lib, rc, what):

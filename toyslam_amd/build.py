@@ -1,4 +1,6 @@
-"""In-tree builds: libtsgo_hip.so (hipcc, gfx950), libtsgo_host.so (g++), graph_optimizer (server)."""
+"""In-tree builds: libtsgo_hip.so (hipcc, gfx950), libtsgo_host.so (g++), graph_optimizer (server) — the product — and
+libtsgo_hip_testing.so: the same sources with -DTSGO_TESTING (test hooks, research variables, the in-process all-reduce group:
+csrc/host/knobs.h, include/tsgo_testing.h), loaded only by the tests that need a hook."""
 import os
 import shutil
 import subprocess
@@ -8,6 +10,7 @@ CSRC = os.path.join(HERE, "csrc")
 HOST_SRC = ["host/problem.cpp", "host/amg.cpp", "host/codec.cpp", "host/synth.cpp", "host/host_api.cpp", "host/errors.cpp"]
 HIP_SO = os.path.join(HERE, "libtsgo_hip.so")
 HOST_SO = os.path.join(HERE, "libtsgo_host.so")
+HIP_TESTING_SO = os.path.join(HERE, "libtsgo_hip_testing.so")
 SERVER = os.path.join(HERE, "graph_optimizer")
 
 
@@ -23,6 +26,7 @@ def _all_sources():
     for root, _d, files in os.walk(CSRC):
         out += [os.path.join(root, f) for f in files if f.endswith((".h", ".hip", ".cpp"))]
     out.append(os.path.join(os.path.dirname(HERE), "include", "tsgo.h"))
+    out.append(os.path.join(os.path.dirname(HERE), "include", "tsgo_testing.h"))
     return out
 
 
@@ -45,6 +49,14 @@ def build_hip(force=False):
     return HIP_SO
 
 
+def build_hip_testing(force=False):
+    if force or _newer(HIP_TESTING_SO, _all_sources()):
+        cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wno-unused-result", "-DTSGO_TESTING",
+               "-o", HIP_TESTING_SO, "tsgo_hip.hip"] + HOST_SRC + ["-lrccl", "-lpthread"]
+        subprocess.check_call(cmd, cwd=CSRC)
+    return HIP_TESTING_SO
+
+
 def build_server(force=False):
     src = os.path.join(CSRC, "host", "server.cpp")
     if not os.path.exists(src):
@@ -57,7 +69,13 @@ def build_server(force=False):
 
 
 def build_all(force=False):
-    return build_host(force), build_hip(force), build_server(force)
+    """The three product binaries (returned) and the testing twin of the HIP library; the two hipcc jobs of the libraries run side by side."""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(3) as ex:
+        jobs = [ex.submit(f, force) for f in (build_hip, build_hip_testing, build_server)]
+        host = build_host(force)
+        hip, _testing, server = [j.result() for j in jobs]
+    return host, hip, server
 
 
 if __name__ == "__main__":

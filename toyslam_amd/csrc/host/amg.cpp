@@ -1,5 +1,6 @@
 // amg.cpp — host-side symbolic setup of the smoothed-aggregation hierarchy (see amg.h).
 #include "amg.h"
+#include "knobs.h"
 #include "parallel.h"
 
 #include <sched.h>
@@ -220,7 +221,7 @@ std::string coarsen(AmgLevel& L, const std::vector<double>& xy, std::vector<char
     // P pattern: aggregates of the row's neighbours
     L.P.n_rows = n; L.P.n_cols = na;
     {
-        std::vector<RowsOut> parts(64);
+        std::vector<RowsOut> parts(kMaxHostThreads);
         const int used = parallel_chunks(n, [&](int c, int b, int e) {
             std::vector<Triple> row;
             RowsOut o;
@@ -277,8 +278,8 @@ WGraph contract(const WGraph& g, const std::vector<int>& cmap, int nc) {
     { std::vector<int> cur(mptr.begin(), mptr.end() - 1); for (int i = 0; i < g.n; ++i) mem[cur[cmap[i]]++] = i; }
     WGraph c; c.n = nc; c.ptr.assign(nc + 1, 0);
     struct Part { std::vector<int> col; std::vector<float> w; };
-    std::vector<Part> parts(64);
-    std::vector<int> first(65, 0);
+    std::vector<Part> parts(kMaxHostThreads);
+    std::vector<int> first(kMaxHostThreads + 1, 0);
     const int used = parallel_chunks(nc, [&](int ch, int b, int e) {
         std::vector<int> mark(nc, -1), pos(nc, 0);
         Part& o = parts[ch];
@@ -470,7 +471,7 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
     struct Tup { int k; uint32_t a, b; int kind; };            // kind 0: landmark pair, 1: odom slot
     struct SOut { std::vector<int> row_nnz, col, n_pair, n_od; std::vector<uint32_t> si, sk, os; };
     if (!schur_elsewhere) {
-        std::vector<SOut> parts(64);
+        std::vector<SOut> parts(kMaxHostThreads);
         const int used = parallel_chunks(P, [&](int c, int b, int e) {
             std::vector<Tup> row;
             SOut o;
@@ -543,21 +544,22 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
     L0.agg.resize(P);
     // aggregate size per level; research override: TSGO_AGG_LIST="8,4,4,8" (last entry repeats) or TSGO_AGG0 / TSGO_AGGC
     std::vector<int> agg_list;
-    if (const char* e = getenv("TSGO_AGG_LIST")) { for (const char* q = e; *q;) { agg_list.push_back(std::max(2, atoi(q))); while (*q && *q != ',') ++q; if (*q == ',') ++q; } }
+    if (const char* e = TSGO_RESEARCH_ENV("TSGO_AGG_LIST")) { for (const char* q = e; *q;) { agg_list.push_back(std::max(2, atoi(q))); while (*q && *q != ',') ++q; if (*q == ',') ++q; } }
     if (agg_list.empty()) {
-        agg_list.push_back(getenv("TSGO_AGG0") ? atoi(getenv("TSGO_AGG0")) : kAggSize);
-        if (getenv("TSGO_AGGC")) agg_list.push_back(atoi(getenv("TSGO_AGGC")));
+        agg_list.push_back(TSGO_RESEARCH_INT("TSGO_AGG0", kAggSize));
+        if (const char* e = TSGO_RESEARCH_ENV("TSGO_AGGC")) agg_list.push_back(atoi(e));
         else for (int m : kAggSizesBelow) agg_list.push_back(m);
     }
     auto agg_at = [&](size_t l) { return agg_list[std::min(l, agg_list.size() - 1)]; };
     const int agg0 = agg_at(0);
-    const int smooth_levels = getenv("TSGO_SMOOTH_LEVELS") ? atoi(getenv("TSGO_SMOOTH_LEVELS")) : kSmoothLevels;
-    const int smooth_from = getenv("TSGO_SMOOTH_FROM") ? atoi(getenv("TSGO_SMOOTH_FROM")) : 0;     // research: tentative prolongators above this level
+    const int smooth_levels = TSGO_RESEARCH_INT("TSGO_SMOOTH_LEVELS", kSmoothLevels);
+    const int smooth_from = TSGO_RESEARCH_INT("TSGO_SMOOTH_FROM", 0);     // research: tentative prolongators above this level
     // research override: TSGO_AGG_MODE=traj cuts the trajectory into runs of consecutive poses instead (the first version)
-    const bool matching = !(getenv("TSGO_AGG_MODE") && std::string(getenv("TSGO_AGG_MODE")) == "traj");
+    const char* agg_mode = TSGO_RESEARCH_ENV("TSGO_AGG_MODE");
+    const bool matching = !(agg_mode && std::string(agg_mode) == "traj");
     WGraph wg; std::vector<int> wkey;
     if (matching) {
-        const float w_od = getenv("TSGO_AGG_WOD") ? (float)atof(getenv("TSGO_AGG_WOD")) : kAggOdomWeight;
+        const float w_od = (float)TSGO_RESEARCH_FLOAT("TSGO_AGG_WOD", kAggOdomWeight);
         wg.n = P; wg.ptr.assign(P + 1, 0);
         for (int i = 0; i < P; ++i) wg.ptr[i + 1] = wg.ptr[i] + (L0.A.ptr[i + 1] - L0.A.ptr[i] - 1);      // every row holds its diagonal block (emit_diag)
         wg.col.resize(wg.ptr[P]); wg.w.resize(wg.ptr[P]);

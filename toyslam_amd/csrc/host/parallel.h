@@ -11,8 +11,11 @@
 
 namespace tsgo {
 
+// Upper bound of parallel_chunks' chunk count, whatever TSGO_HOST_THREADS says: callers keep per-chunk outputs in arrays of this size.
+constexpr int kMaxHostThreads = 64;
+
 inline int host_threads() {
-    if (const char* e = getenv("TSGO_HOST_THREADS")) return std::max(1, atoi(e));
+    if (const char* e = getenv("TSGO_HOST_THREADS")) return std::max(1, std::min(kMaxHostThreads, atoi(e)));
     cpu_set_t set; CPU_ZERO(&set);
     int n = 0;
     if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);

@@ -1,5 +1,6 @@
 // problem.cpp — builds the device-ready layout (see problem.h) from a tsgo_graph.
 #include "problem.h"
+#include "knobs.h"
 #include "parallel.h"
 
 #include <algorithm>
@@ -188,8 +189,8 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
 
     // ---- internal numbering --------------------------------------------------------------------------
     // poses: global (identical on every shard) -> sort by the FULL graph's LM degree
-    static const int win_pose = getenv("TSGO_SORT_WINDOW_POSE") ? atoi(getenv("TSGO_SORT_WINDOW_POSE")) : kSortWindow;     // research
-    static const int win_lm = getenv("TSGO_SORT_WINDOW_LM") ? atoi(getenv("TSGO_SORT_WINDOW_LM")) : kSortWindow;
+    static const int win_pose = TSGO_RESEARCH_INT("TSGO_SORT_WINDOW_POSE", kSortWindow);     // research
+    static const int win_lm = TSGO_RESEARCH_INT("TSGO_SORT_WINDOW_LM", kSortWindow);
     const std::vector<int> pose_order = window_sort(deg_pose_lm, win_pose);       // internal -> class
     std::vector<int> pose_internal(P);
     for (int i = 0; i < P; ++i) pose_internal[pose_order[i]] = i;

@@ -5,7 +5,9 @@
 //   RULES "python" or "python:LR": the loop of the reference's in-process Python optimizer instead (lambda * I damping, step LR,
 //   default 0.2 as slam_main.py passes); ODOM_JACOBIAN "analytic": the extension of tsgo_config.odom_jacobian.  Both default to
 //   what the reference's C++ server does.  WARM_REQUESTS 1: tsgo_config.warm_requests (a connection's next request starts its PCG
-//   solves from the history of its last one; same answers to PCG_TOL), 0: every request starts from nothing.
+//   solves from the history of ITS OWN last one when it gets the same engine handle back; a handle that last served another
+//   connection forgets that history first, so no client's iteration counts or low-order bits depend on other clients' traffic;
+//   same answers to PCG_TOL), 0: every request starts from nothing.
 //
 // Positional arguments 1-5 are the reference's (remote/app/main.cpp:12-16, README.md:15-18).  The
 // reference maps PIPELINE "cpu" -> CPU optimizer and anything else -> GPU, SOLVER "eigen" -> Eigen and
@@ -41,6 +43,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <utility>
 #include <vector>
 
 #include "../../../include/tsgo.h"
@@ -80,6 +83,8 @@ struct Server {
     tsgo_config cfg;
     int max_engines = 2;
     std::vector<tsgo_optimizer*> idle;      // engine handles not in use
+    std::vector<std::pair<tsgo_optimizer*, uint64_t>> last_user;   // per handle: the session it served last (pool_mutex)
+    uint64_t next_session = 1;
     int created = 0;
     std::mutex pool_mutex;
     std::condition_variable pool_cv;
@@ -120,6 +125,15 @@ struct Server {
         { std::lock_guard<std::mutex> lock(pool_mutex); idle.push_back(o); }
         pool_cv.notify_one();
     }
+    uint64_t new_session() { std::lock_guard<std::mutex> lock(pool_mutex); return next_session++; }
+    // The handle now serves `session`: true when the last request it served was another session's (or nobody's).  The solver
+    // history a handle keeps under WARM_REQUESTS belongs to the connection whose requests built it.
+    bool changes_hands(tsgo_optimizer* o, uint64_t session) {
+        std::lock_guard<std::mutex> lock(pool_mutex);
+        for (auto& e : last_user) if (e.first == o) { const bool other = e.second != session; e.second = session; return other; }
+        last_user.emplace_back(o, session);
+        return true;
+    }
 
     // one request: remote/app/ConnectionHandler.h:14-34
     // What a connection keeps from message to message (the reference re-creates everything per message,
@@ -140,6 +154,7 @@ struct Server {
         std::vector<double> v_pos;
         tsgo_wire_graph* w = tsgo_wire_new();
         tsgo_optimizer* last_engine = nullptr;
+        uint64_t id = 0;
         ~Session() { tsgo_wire_free(w); }
     };
 
@@ -159,6 +174,8 @@ struct Server {
             tsgo_optimizer* opt = acquire(last_engine);
             if (!opt) { std::cerr << tsgo_last_error() << std::endl; return false; }
             last_engine = opt;
+            const bool fresh_hands = changes_hands(opt, ss.id);
+            if (fresh_hands) tsgo_reset_history(opt);      // another connection's deltas must not seed this one's solves
             struct Give { Server& s; tsgo_optimizer* o; ~Give() { s.release(o); } } give{*this, opt};
             BlockTimer t{"OptimizeHIP"};
             tsgo_stats st;
@@ -171,7 +188,7 @@ struct Server {
                 std::cout << "Summary() error = " << st.chi2_last << std::endl;                        // :182
                 std::cout << " [hip] iterations=" << st.iterations_run << " pcg_iters=" << st.pcg_iters_total
                           << (st.structure_reused ? " structure=reused refill=" : " structure=built setup=") << st.ms_setup << "ms linearize=" << st.ms_linearize << "ms solve=" << st.ms_solve
-                          << "ms update=" << st.ms_update << "ms" << std::endl;
+                          << "ms update=" << st.ms_update << "ms history=" << st.history_carried << std::endl;
             }
         }
         if (ok) {
@@ -195,7 +212,7 @@ struct Server {
         std::cout << "\n------ New Connection ------\n";                         // ConnectionHandler.h:10
         int one = 1; setsockopt(fd, IPPROTO_TCP, TCP_NODELAY, &one, sizeof(one));
         try {                                        // bad_alloc and friends end THIS connection, not the server (the thread is detached)
-            Session ss;
+            Session ss; ss.id = new_session();
             Bytes& payload = ss.payload;
             size_t window_max = 0; int window_n = 0;
             for (;;) {

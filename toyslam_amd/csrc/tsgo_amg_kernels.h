@@ -579,6 +579,96 @@ __global__ __launch_bounds__(kDenseThreads) void k_coarse_tail(int n, int n_agg,
     }
 }
 
+// ---- the bottom of the V-cycle as ONE dense operator (round 4) ---------------------------------------------------------------------
+// On the last explicit level (n <= 256 block rows; 122 at 100k poses) the cycle is: pre-sweep z1 = W r (W = omega D^-1), coarse
+// correction through the dense inverse C of the level below, z2 = z1 + P C P^T (r - A z1), post-sweep z3 = z2 + W (r - A z2).  That is a
+// LINEAR map of r, and with S = I - W A, E = S P it reads
+//     z3 = B r,   B = W + S W + E C E^T                      (symmetric: W A W, E C E^T and W are)
+// so it is formed once per hierarchy build (five tiny launches, dense arithmetic in T, 0.5 (B + B^T) stored as f32: exactly symmetric)
+// and APPLIED as one dense matrix-vector product per PCG iteration — instead of residual, restrict + dense solve + prolong (one workgroup,
+// ~10 us) and post-sweep: three dependent launches, 17-19 us of the 217 an iteration takes at 100k poses, for the same operator.
+// The level's matrix has 92 blocks per row of 122: it IS dense.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bottom_scatter(int nnzA, const int* __restrict__ a_row, const int* __restrict__ a_col, const HT<T>* __restrict__ A,
+                                                           const HT<T>* __restrict__ Dinv, const T* __restrict__ omega_ptr, int nnzP, const int* __restrict__ p_row,
+                                                           const int* __restrict__ p_col, const HT<T>* __restrict__ P, int n3, int nd, T* __restrict__ Sd, T* __restrict__ Pd) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t < nnzA) {           // S = I - omega D^-1 A, block (i, j)
+        const int i = a_row[t], j = a_col[t];
+        const T w = *omega_ptr;
+        T d[9], a[9], m[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { d[k] = Dinv[(size_t)i * 9 + k]; a[k] = A[(size_t)t * 9 + k]; }
+        m3_mul_acc<T>(d, a, m);
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) Sd[(size_t)(3 * i + x) * n3 + 3 * j + y] = (i == j && x == y ? T(1) : T(0)) - w * m[3 * x + y];
+    } else if (t - nnzA < nnzP) {
+        const int pb = t - nnzA, i = p_row[pb], c = p_col[pb];
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) Pd[(size_t)(3 * i + x) * nd + 3 * c + y] = T(P[(size_t)pb * 9 + 3 * x + y]);
+    }
+}
+
+// C[M x N] = A[M x K] * B, B given as [K x N] (TB = 0) or as [N x K] (TB = 1: C = A B^T); row-major, 16 x 16 tiles through LDS.
+template <typename T, int TB>
+__global__ __launch_bounds__(256) void k_small_gemm(int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, T* __restrict__ C, int ldc) {
+    __shared__ T sa[16][17], sb[16][17];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+    T acc = 0;
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        sa[ty][tx] = (row < M && k0 + tx < K) ? A[(size_t)row * lda + k0 + tx] : T(0);
+        if (TB) { const int n = blockIdx.x * 16 + ty; sb[tx][ty] = (n < N && k0 + tx < K) ? B[(size_t)n * ldb + k0 + tx] : T(0); }      // sb[k][n]
+        else sb[ty][tx] = (k0 + ty < K && col < N) ? B[(size_t)(k0 + ty) * ldb + col] : T(0);
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc += sa[ty][k] * sb[k][tx];
+        __syncthreads();
+    }
+    if (row < M && col < N) C[(size_t)row * ldc + col] = acc;
+}
+
+// Bf = f32(0.5 (B + B^T)), B = W + S W + G with G = E C E^T already in Bd; W = omega D^-1 block diagonal.  One thread per entry; the
+// entry and its mirror are both evaluated by the thread (and again, in the other order, by the mirror's thread: a + b == b + a).
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bottom_finish(int n3, const T* __restrict__ Sd, const HT<T>* __restrict__ Dinv, const T* __restrict__ omega_ptr,
+                                                          const T* __restrict__ Bd, float* __restrict__ Bf) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n3 * n3) return;
+    const int r = t / n3, c = t % n3;
+    const T w = *omega_ptr;
+    auto entry = [&](int rr, int cc) {
+        const int jb = cc / 3, y = cc % 3;
+        T v = Bd[(size_t)rr * n3 + cc];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) v += Sd[(size_t)rr * n3 + 3 * jb + k] * (w * T(Dinv[(size_t)jb * 9 + 3 * k + y]));
+        if (rr / 3 == jb) v += w * T(Dinv[(size_t)jb * 9 + 3 * (rr % 3) + y]);
+        return v;
+    };
+    Bf[(size_t)r * n3 + c] = (float)(T(0.5) * (entry(r, c) + entry(c, r)));
+}
+
+// z = B r, one wavefront per row (n3 <= 768 rows: every row is one coalesced pass), the level's whole cycle in one launch
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_bottom_apply(int n3, const float* __restrict__ Bf, const T* __restrict__ r, T* __restrict__ z, const CgState<T>* __restrict__ st) {
+    const int done = st->done;
+    const int row = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    const int rc = row < n3 ? row : n3 - 1;
+    const float* b = Bf + (size_t)rc * n3;
+    T acc = 0;
+    float b0 = lane < n3 ? b[lane] : 0.f;
+    issue_before_exit(b0);
+    if (done) return;
+    if (lane < n3) acc = T(b0) * r[lane];
+    for (int c = lane + 64; c < n3; c += 64) acc += T(b[c]) * r[c];
+    acc = wave_sum<T>(acc);
+    if (row < n3 && lane == 0) z[row] = acc;
+}
+
 // coarsest level alone (graphs with a single explicit level): z = inv r, single workgroup
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_dense_apply(int n, const T* __restrict__ inv, const T* __restrict__ r, T* __restrict__ z,

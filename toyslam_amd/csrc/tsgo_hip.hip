@@ -23,8 +23,12 @@
 #include <vector>
 
 #include "../../include/tsgo.h"
+#ifdef TSGO_TESTING
+#include "../../include/tsgo_testing.h"
+#endif
 #include "host/amg.h"
 #include "host/errors.h"
+#include "host/knobs.h"
 #include "host/parallel.h"
 #include "host/problem.h"
 #include "tsgo_amg_kernels.h"
@@ -89,6 +93,7 @@ using namespace tsgo;
 
 }  // namespace
 
+#ifdef TSGO_TESTING
 // An all-reduce among engine handles of ONE process (typically sharing one device): every rank stages its buffer in host
 // memory, all ranks meet, every rank sums the staged buffers in rank order (same bits everywhere, as with RCCL) and copies
 // the sum back.  Slow by design; it exists so that the edge-sharded device path (shard tables, ownership rules, per-rank
@@ -115,6 +120,9 @@ struct tsgo_local_group {
     }
     static constexpr int kLocalBarrierSeconds = 120;
 };
+#else
+struct tsgo_local_group;      // in-process all-reduce group: TSGO_TESTING builds only (include/tsgo_testing.h)
+#endif
 
 namespace {
 
@@ -133,8 +141,9 @@ struct IEngine {
     virtual int cycle_probe(int reps, tsgo_cycle_level* out, int cap) = 0;
     virtual int profile_iteration(int reps, tsgo_prof_entry* out, int cap) = 0;
     virtual int comm_selftest(int* ranks_out) = 0;
+    virtual void reset_history() = 0;
     ncclComm_t comm = nullptr;
-    tsgo_local_group* lgroup = nullptr;      // in-process stand-in for the communicator (tests on a one-GPU box)
+    tsgo_local_group* lgroup = nullptr;      // in-process stand-in for the communicator (tests on a one-GPU box; always null outside TSGO_TESTING builds)
 };
 
 constexpr int kRhoSteps = 16, kRhoBlocks = 64, kRhoEvery = 8;   // smoother-damping estimate: power steps, partial sums, refresh period
@@ -286,14 +295,28 @@ template <typename T> struct Engine : IEngine {
     int n_cycle_f32_switches = 0;
     size_t cyw() const { return cy16 ? (size_t)kCyWordsF16 : (size_t)kCyWordsF32; }
 
+    // Environment, read ONCE per handle (tsgo_create).  Operational: verbosity / timing traces.  Research and test hooks
+    // (TSGO_RESEARCH_ENV: only builds with -DTSGO_TESTING see them, host/knobs.h).
+    bool say_env = false, solve_timing = false, stage_timing = false;
+    bool hook_inject_amg_failure = false;      // TSGO_INJECT_AMG_FAILURE: the first multigrid solve of every tsgo_optimize is declared broken down
+    bool hook_force_host_slow = false;         // TSGO_FORCE_HOST_SLOW: the handle believes its host thread is too slow for eager launches
+    bool hook_force_paced = false;             // TSGO_FORCE_PACED: paced eager launches from the first solve on (no timing heuristics)
+    int pace_lead = kPaceLead;                 // TSGO_PACE_LEAD: iterations enqueued ahead of the gate that has reported
     explicit Engine(const tsgo_config& c) : cfg(c) {
-        if (const char* e = getenv("TSGO_SWEEPS_LIST")) for (const char* q = e; *q;) { sweeps_list.push_back(std::max(1, std::min(4, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
+        say_env = c.verbose || getenv("TSGO_VERBOSE") != nullptr;
+        solve_timing = getenv("TSGO_SOLVE_TIMING") != nullptr;
+        stage_timing = getenv("TSGO_STAGE_TIMING") != nullptr;
+        if (const char* e = TSGO_RESEARCH_ENV("TSGO_SWEEPS_LIST")) for (const char* q = e; *q;) { sweeps_list.push_back(std::max(1, std::min(4, atoi(q)))); while (*q && *q != ',') ++q; if (*q == ',') ++q; }
         explicit0 = c.cycle_level0 != 0;
         cy16 = c.cycle_storage != 32;
-        if (const char* e = getenv("TSGO_HOST_PRODUCTS")) device_products = atoi(e) == 0;
-        if (const char* e = getenv("TSGO_SYM_DECLINE")) sym_decline = atoi(e);
-        if (const char* e = getenv("TSGO_HIER_MAX_AGE")) hier_max_age = std::max(1, atoi(e));
-        if (const char* e = getenv("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
+        if (const char* e = TSGO_RESEARCH_ENV("TSGO_HOST_PRODUCTS")) device_products = atoi(e) == 0;
+        if (const char* e = TSGO_RESEARCH_ENV("TSGO_SYM_DECLINE")) sym_decline = atoi(e);
+        if (const char* e = TSGO_RESEARCH_ENV("TSGO_HIER_MAX_AGE")) hier_max_age = std::max(1, atoi(e));
+        if (const char* e = TSGO_RESEARCH_ENV("TSGO_HIER_SLACK")) hier_slack = std::max(0, atoi(e));
+        if (const char* e = TSGO_RESEARCH_ENV("TSGO_PACE_LEAD")) pace_lead = std::max(1, atoi(e));
+        hook_inject_amg_failure = TSGO_RESEARCH_ENV("TSGO_INJECT_AMG_FAILURE") != nullptr;
+        hook_force_host_slow = TSGO_RESEARCH_ENV("TSGO_FORCE_HOST_SLOW") != nullptr;
+        hook_force_paced = TSGO_RESEARCH_ENV("TSGO_FORCE_PACED") != nullptr;
     }
 
     ~Engine() override { release(); for (Slab& sl : slabs) (void)hipFree(sl.base); if (carry_dev) (void)hipFree(carry_dev); if (stage) (void)hipHostFree(stage); if (stream) (void)hipStreamDestroy(stream); if (stream2) (void)hipStreamDestroy(stream2); for (auto& e : ev) if (e) (void)hipEventDestroy(e); for (auto& m : prof) (void)hipEventDestroy(m.e); }
@@ -638,6 +661,36 @@ template <typename T> struct Engine : IEngine {
         if (h_rho) (void)hipHostFree(h_rho);
         HIP_OK(hipHostMalloc((void**)&h_rho, sizeof(T) * 16 * 2 * kRhoBlocks));
         lin_count = 0; hier_age = -1;
+        // the bottom of the cycle as one dense operator (tsgo_amg_kernels.h: k_bottom_*): the last explicit level when it is small enough
+        bottom_dense = lv.size() >= 2 && lv.back().n * 4 <= kDenseThreads && nb_last > 0;
+        if (bottom_dense) {
+            const size_t n3 = (size_t)lv.back().n * 3, nd = (size_t)nb_last * 3;
+            if (int rc = dalloc(&bot_S, n3 * n3)) return rc;
+            if (int rc = dalloc(&bot_B, n3 * n3)) return rc;
+            if (int rc = dalloc(&bot_P, n3 * nd)) return rc;
+            if (int rc = dalloc(&bot_E, n3 * nd)) return rc;
+            if (int rc = dalloc(&bot_F, n3 * nd)) return rc;
+            if (int rc = dalloc(&bot_Bf, n3 * n3)) return rc;
+        }
+        return 0;
+    }
+    bool bottom_dense = false;
+    T *bot_S = nullptr, *bot_B = nullptr, *bot_P = nullptr, *bot_E = nullptr, *bot_F = nullptr; float* bot_Bf = nullptr;
+    // B = W + S W + E C E^T of the last explicit level (after k_dense_inverse, and again whenever the level's damping changes)
+    int launch_bottom_setup() {
+        if (!bottom_dense) return 0;
+        DevLevel<T>& L = lv.back();
+        const int n3 = L.n * 3, nd = nb_last * 3;
+        const T* om = omega_dev + (lv.size() - 1);
+        HIP_OK(hipMemsetAsync(bot_S, 0, sizeof(T) * (size_t)n3 * n3, stream));
+        HIP_OK(hipMemsetAsync(bot_P, 0, sizeof(T) * (size_t)n3 * nd, stream));
+        hipLaunchKernelGGL((k_bottom_scatter<T>), dim3(grid_for(L.nnzA + L.nnzP)), dim3(kBlock), 0, stream, L.nnzA, (const int*)L.A_row, (const int*)L.A_col, (const H*)L.A, (const H*)L.Dinv, om,
+                           L.nnzP, (const int*)L.P_row, (const int*)L.P_col, (const H*)L.P, n3, nd, bot_S, bot_P);
+        auto tiles = [](int n) { return (unsigned)((n + 15) / 16); };
+        hipLaunchKernelGGL((k_small_gemm<T, 0>), dim3(tiles(nd), tiles(n3)), dim3(256), 0, stream, n3, nd, n3, (const T*)bot_S, n3, (const T*)bot_P, nd, bot_E, nd);          // E = S P
+        hipLaunchKernelGGL((k_small_gemm<T, 0>), dim3(tiles(nd), tiles(n3)), dim3(256), 0, stream, n3, nd, nd, (const T*)bot_E, nd, (const T*)inv_last, nd, bot_F, nd);      // F = E C
+        hipLaunchKernelGGL((k_small_gemm<T, 1>), dim3(tiles(n3), tiles(n3)), dim3(256), 0, stream, n3, n3, nd, (const T*)bot_F, nd, (const T*)bot_E, nd, bot_B, n3);         // G = F E^T
+        hipLaunchKernelGGL((k_bottom_finish<T>), dim3(grid_for(n3 * n3)), dim3(kBlock), 0, stream, n3, (const T*)bot_S, (const H*)L.Dinv, om, (const T*)bot_B, bot_Bf);
         return 0;
     }
 #undef UP
@@ -671,7 +724,7 @@ template <typename T> struct Engine : IEngine {
         const size_t o_p = 0, o_l = o_p + 4 * Sp, o_o = o_l + 4 * Sl, o_ps = o_o + 9 * So, o_th = o_ps + 4 * P, o_lm = o_th + P, total = o_lm + (size_t)kLmRec * std::max<size_t>(L, 1);
         if (int rc = stage_reserve(total)) return rc;
         const size_t nE = (size_t)g.n_edges;
-        static const bool timing = getenv("TSGO_STAGE_TIMING") != nullptr;
+        const bool timing = stage_timing;
         auto t_last = std::chrono::steady_clock::now();
         auto lap = [&](const char* what) {
             if (!timing) return;
@@ -817,6 +870,10 @@ template <typename T> struct Engine : IEngine {
         return 0;
     }
 
+    // tsgo_reset_history: the next tsgo_set_graph starts the solver from nothing, whatever warm_requests says (a pooled handle
+    // changing hands: one client's deltas must not seed another client's solves)
+    void reset_history() override { have_prev = false; n_prev = 0; n_tested = 0; carried = false; carry.n = 0; }
+
     int refill(const tsgo_graph& g) {
         const auto t0 = std::chrono::steady_clock::now();
         const int rc = refill_values(g);
@@ -825,7 +882,7 @@ template <typename T> struct Engine : IEngine {
         if (rc) { have_graph_data = false; return rc; }
         ++structure_reuses;
         ms_setup = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        if (cfg.verbose || getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] set_graph: same structure as the previous graph: values refilled in %.1f ms\n", ms_setup);
+        if (say_env) std::fprintf(stderr, "[tsgo] set_graph: same structure as the previous graph: values refilled in %.1f ms\n", ms_setup);
         return 0;
     }
     int refill_values(const tsgo_graph& g) {
@@ -868,7 +925,7 @@ template <typename T> struct Engine : IEngine {
         od_live = -1;
         if (!err.empty()) return set_error(-2, "tsgo_set_graph: " + err);
         pr.odom_analytic = oj();
-        const bool say = cfg.verbose || getenv("TSGO_VERBOSE");
+        const bool say = say_env;
         auto lap = [&, last = t0](const char* what) mutable {
             const auto n = std::chrono::steady_clock::now();
             if (say) std::fprintf(stderr, "[tsgo] set_graph: %-34s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - last).count());
@@ -1053,7 +1110,7 @@ template <typename T> struct Engine : IEngine {
             if (l + 1 < lv.size()) do { if (cy16) hipLaunchKernelGGL((k_to_planes<T, 1>), dim3(grid_for(lv[l + 1].n, 8)), dim3(kBlock), 0, stream, lv[l + 1].n, (const int*)lv[l + 1].A_ptr, (const H*)lv[l + 1].A, lv[l + 1].Apm); else hipLaunchKernelGGL((k_to_planes<T, 0>), dim3(grid_for(lv[l + 1].n, 8)), dim3(kBlock), 0, stream, lv[l + 1].n, (const int*)lv[l + 1].A_ptr, (const H*)lv[l + 1].A, lv[l + 1].Apm); } while (0);
         }
         hipLaunchKernelGGL((k_dense_inverse<T>), dim3(1), dim3(kDenseThreads), 0, stream, nb_last, last_ptr, last_col, (const H*)A_last, inv_last);
-        return 0;
+        return launch_bottom_setup();
     }
 
     static int lanes_for(double avg_row) {
@@ -1140,7 +1197,7 @@ template <typename T> struct Engine : IEngine {
             }
             om[l] = (T)w; omega_host[l] = w;
         }
-        if (cfg.verbose || getenv("TSGO_VERBOSE")) { std::fprintf(stderr, "[tsgo] smoother damping per level:"); for (size_t l = 0; l < nl; ++l) std::fprintf(stderr, " %.3f", omega_host[l]); std::fprintf(stderr, "\n"); }
+        if (say_env) { std::fprintf(stderr, "[tsgo] smoother damping per level:"); for (size_t l = 0; l < nl; ++l) std::fprintf(stderr, " %.3f", omega_host[l]); std::fprintf(stderr, "\n"); }
         HIP_OK(hipMemcpyAsync(omega_dev, om.data(), 16 * sizeof(T), hipMemcpyHostToDevice, stream));
         HIP_OK(hipStreamSynchronize(stream));
         return 0;
@@ -1169,12 +1226,14 @@ template <typename T> struct Engine : IEngine {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
             if (nl > 1) PF(bytes_transfer(L, 2), "restrict from L0", "k_restrict<%s, %d, 1, %d>", tname(), lpr, cy16 ? 1 : 0);
-            if (nl > 1) launch_restrict<1>(lpr, L, (const T*)r, (const T*)sbuf, lv[1].r, (const H*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
+            if (nl > 1) launch_restrict<1>(lpr, L, (const T*)r, (const T*)sbuf, lv[1].r, (bottom_dense && nl == 2) ? (const H*)nullptr : (const H*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
         }
         // coarse levels: V(nu,nu) with nu = coarse_sweeps block-Jacobi sweeps (the first pre-sweep comes fused
         // with the restriction above).  The current iterate alternates between L.z and L.z2; it ends in L.z2.
+        const bool dense_bottom = bottom_dense && nl > 1;      // the last explicit level's whole cycle is one dense product (k_bottom_apply)
         for (size_t l = 1; l < nl; ++l) {
             DevLevel<T>& L = lv[l];
+            if (dense_bottom && l + 1 == nl) break;
             const int nu = nu_at(l);
             const int lprA = lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n);
             T* cur = L.z; T* oth = L.z2;
@@ -1187,14 +1246,20 @@ template <typename T> struct Engine : IEngine {
             launch_sweep<0>(lprA, L, (const T*)L.r, (const T*)cur, L.res, (const T*)(omega_dev + l), s);
             if (l + 1 < nl) {
                 const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
+                const bool into_dense = dense_bottom && l + 2 == nl;      // the dense operator pre-smooths by itself
                 PF(bytes_transfer(L, 1), lvl("restrict from", l).c_str(), "k_restrict<%s, %d, 0, %d>", tname(), lpr, cy16 ? 1 : 0);
-                launch_restrict<0>(lpr, L, (const T*)L.res, (const T*)L.res, lv[l + 1].r, (const H*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
+                launch_restrict<0>(lpr, L, (const T*)L.res, (const T*)L.res, lv[l + 1].r, into_dense ? (const H*)nullptr : (const H*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
             }
         }
         // iterate of level l after the down pass: L.z when nu is odd, L.z2 when even
         auto down_iter = [&](DevLevel<T>& L, int nu) { return (nu % 2) ? L.z : L.z2; };
         auto down_other = [&](DevLevel<T>& L, int nu) { return (nu % 2) ? L.z2 : L.z; };
-        if (nl > 1 && lv[nl - 1].n * 4 <= kDenseThreads) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
+        if (dense_bottom) {      // z2 = B r: pre-sweep, coarse correction through the dense inverse and post-sweep of the last explicit level at once
+            DevLevel<T>& L = lv[nl - 1];
+            const int n3 = L.n * 3;
+            PF((double)n3 * n3 * sizeof(float) + 2.0 * n3 * sizeof(T), lvl("whole cycle of", nl - 1).c_str(), "k_bottom_apply<%s>", tname());
+            hipLaunchKernelGGL((k_bottom_apply<T>), dim3(grid_for(n3, 64)), dim3(kBlock), 0, stream, n3, (const float*)bot_Bf, (const T*)L.r, L.z2, s);
+        } else if (nl > 1 && lv[nl - 1].n * 4 <= kDenseThreads) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
             DevLevel<T>& L = lv[nl - 1];
             PF(2.0 * L.nnzP * (9 * sizeof(H) + 4) + (double)nb_last * 3 * nb_last * 3 * sizeof(T) + L.n * 6.0 * sizeof(T), lvl("restrict + dense solve + prolong", nl - 1).c_str(), "k_coarse_tail<%s>", tname());
             hipLaunchKernelGGL((k_coarse_tail<T>), dim3(1), dim3(kDenseThreads), 0, stream, L.n, L.n_agg, L.R_ptr, L.R_col, (const H*)L.Rv, L.P_ptr, L.P_col, (const H*)L.P,
@@ -1215,6 +1280,7 @@ template <typename T> struct Engine : IEngine {
         }
         for (size_t l = nl - 1; l >= 1; --l) {
             DevLevel<T>& L = lv[l];
+            if (dense_bottom && l + 1 == nl) continue;      // its result is in L.z2 already
             const int nu = nu_at(l);
             T* cur = down_iter(L, nu); T* oth = down_other(L, nu);
             if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, cur, 3, s, l);
@@ -1267,6 +1333,7 @@ template <typename T> struct Engine : IEngine {
     // split graph — and by a single shard that was given a communicator (tsgo_comm_init with world = 1), which is how
     // the RCCL plumbing is exercised on a one-GPU box.
     bool collective() const { return pr.world > 1 || comm != nullptr || lgroup != nullptr; }
+#ifdef TSGO_TESTING
     template <typename U> int allreduce_local(U* buf, size_t n) {
         tsgo_local_group& G = *lgroup;
         std::vector<unsigned char>& mine = G.stage[cfg.rank];
@@ -1285,6 +1352,9 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipStreamSynchronize(stream));
         return 0;
     }
+#else
+    template <typename U> int allreduce_local(U*, size_t) { return set_error(-12, "the in-process all-reduce group exists in TSGO_TESTING builds only"); }
+#endif
     int allreduce(T* buf, size_t n) {
         if (!collective()) return 0;
         if (lgroup) return allreduce_local(buf, n);
@@ -1306,7 +1376,9 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipSetDevice(cfg.device));
         int n = 1;
         if (comm) NCCL_OK(ncclCommCount(comm, &n));
+#ifdef TSGO_TESTING
         else if (lgroup) n = lgroup->world;
+#endif
         if (ranks_out) *ranks_out = n;
         if (!collective()) return 0;
         T* d = nullptr;
@@ -1352,6 +1424,7 @@ template <typename T> struct Engine : IEngine {
                 hier_age = 0;
                 if (lin_count++ % kRhoEvery == 0) {
                     if (int rc = estimate_damping()) return rc;
+                    if (int rc = launch_bottom_setup()) return rc;      // the dense bottom operator holds the last level's damping
                     launch_finalize();        // zc = omega_0 Minv r with the fresh omega_0
                 }
             }
@@ -1403,7 +1476,7 @@ template <typename T> struct Engine : IEngine {
         }
         carried = false;
         if (int rc = do_solve_once(iters, fail)) return rc;
-        static const bool warm_trace = getenv("TSGO_SOLVE_TIMING") != nullptr;
+        const bool warm_trace = solve_timing;
         if (warm_trace && warmed) {
             int order = 0; T gs = 0; std::vector<T> e((size_t)kMaxWarm * nbC);
             if (int rc = copy_sync(&order, warm_order_dev, sizeof(int), hipMemcpyDeviceToHost)) return rc;
@@ -1423,7 +1496,7 @@ template <typename T> struct Engine : IEngine {
             // repeated with them.
             cy16 = false; ++n_cycle_f32_switches;
             if (cg_graph) { (void)hipGraphExecDestroy(cg_graph); cg_graph = nullptr; optimize_calls_on_tables = 1; }     // it holds the packed kernels; re-captured at the next tsgo_optimize
-            if (cfg.verbose || getenv("TSGO_VERBOSE")) std::fprintf(stderr, "[tsgo] %d PCG iterations (fail %d) with the packed cycle format: this structure's cycle switches to f32 copies\n", *iters, *fail);
+            if (say_env) std::fprintf(stderr, "[tsgo] %d PCG iterations (fail %d) with the packed cycle format: this structure's cycle switches to f32 copies\n", *iters, *fail);
             if (int rc = launch_amg_setup()) return rc;
             hier_age = 0; iters_fresh = 0;
             if (*fail != 0) {
@@ -1449,7 +1522,7 @@ template <typename T> struct Engine : IEngine {
         }
         // test hook: TSGO_INJECT_AMG_FAILURE=1 treats the first multigrid solve of every tsgo_optimize call as broken down, so that the
         // block-Jacobi repeat below runs on a graph where the cycle is perfectly healthy (tests/test_gpu_parity.py)
-        const bool inject = getenv("TSGO_INJECT_AMG_FAILURE") != nullptr;
+        const bool inject = hook_inject_amg_failure;
         if (inject && amg_on && inject_armed) { inject_armed = false; *fail = 1; }
         if (*fail == 1 && amg_on) {
             ++n_fallbacks;
@@ -1472,43 +1545,56 @@ template <typename T> struct Engine : IEngine {
     // not drained at the end of the solve — the back-substitution queues up behind the last exits (profiles/r03z_paced_eager.txt).
     double ref_us_per_iter = 0;        // the device's time per iteration as the burst path measured it (the structure's first solves)
     int n_paced_slow = 0;
+    uint32_t paced_base = 0;           // sequence numbers grow ACROSS solves: a gate of an earlier solve that is still queued when a retry
+                                       // starts the next one (pace_lead > 1, hierarchy / block-Jacobi repeats) reports a number <= base and is ignored
     int do_solve_paced(int* iters, int* fail) {
         uint64_t* hw = reinterpret_cast<uint64_t*>(h_flag);
-        __atomic_store_n(hw, (uint64_t)0, __ATOMIC_SEQ_CST);
-        static const bool timing = getenv("TSGO_SOLVE_TIMING") != nullptr;
+        if (paced_base > 0x70000000u) {      // (wrap-around: once per 4e9 iterations) nothing may be in flight when the numbering restarts
+            HIP_OK(hipStreamSynchronize(stream));
+            paced_base = 0; __atomic_store_n(hw, (uint64_t)0, __ATOMIC_SEQ_CST);
+        }
+        const uint32_t base = paced_base;
+        const bool timing = solve_timing;
         const auto w0 = std::chrono::steady_clock::now();
         auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count(); };
-        static const int pace_lead = getenv("TSGO_PACE_LEAD") ? std::max(1, atoi(getenv("TSGO_PACE_LEAD"))) : kPaceLead;      // research
-        int launched = 0; long spins = 0;
+        int launched = 0, seen_last = 0; long spins = 0;
+        double t_last_gate = 0;        // when the newest gate was seen (or the last launch made): a healthy long solve keeps moving this
         uint64_t w = 0;
         for (;;) {
             w = __atomic_load_n(hw, __ATOMIC_ACQUIRE);      // seq << 32 | done << 31 | fail << 28 | iterations completed (k_iter_gate)
-            const int seen = (int)(w >> 32);
+            const int32_t rel = (int32_t)((uint32_t)(w >> 32) - base);
+            const int seen = rel > 0 ? (int)rel : 0;          // reports of earlier solves count as "nothing seen yet"
+            if (seen != seen_last) { seen_last = seen; t_last_gate = since(); }
             if (seen > 0 && ((w >> 31) & 1)) break;
             if (launched - seen < pace_lead) {
-                if (launched > cfg.pcg_max_iters + 4) return set_error(-20, "PCG did not terminate");
-                if (int rc = launch_iteration(launched & 1, launched + 1)) return rc;
-                ++launched; spins = 0;
+                if (launched > cfg.pcg_max_iters + 4) { paced_base = base + (uint32_t)launched; return set_error(-20, "PCG did not terminate"); }
+                if (int rc = launch_iteration(launched & 1, (int)(base + (uint32_t)launched + 1u))) { paced_base = base + (uint32_t)launched + 1u; return rc; }
+                ++launched; spins = 0; t_last_gate = since();
             } else {
                 __builtin_ia32_pause();
                 if ((spins & 0x3f) == 0x3f) std::this_thread::yield();      // the device needs ~120 us before the next iteration has to be on its way: other threads may have the core
-                if ((++spins & 0xfffff) == 0 && since() > 30e6) return set_error(-20, "PCG: the device stopped reporting (30 s without a gate)");
+                if ((++spins & 0xfffff) == 0 && since() - t_last_gate > 30e6) { paced_base = base + (uint32_t)launched; return set_error(-20, "PCG: the device stopped reporting (30 s without a gate)"); }
             }
         }
+        paced_base = base + (uint32_t)launched;
         *iters = (int)(w & 0x0fffffffu); *fail = (int)((w >> 28) & 7);
         const double wall = since();
         if (timing) std::fprintf(stderr, "[tsgo] solve (paced): %d iterations launched, done reported after %d at %.0f us\n", launched, *iters, wall);
         predicted_cg = *iters;
         if (amg_on && hier_age >= 0 && hier_age < kAgeSlots) iters_by_age[hier_age] = *fail ? 0 : *iters;
         // a host that cannot stay ahead shows as iterations that take longer than the burst path measured: then the handle goes over to replay
-        if (cfg.use_graphs == 2 && *iters >= 8 && !*fail && ref_us_per_iter > 0) {
+        if (cfg.use_graphs == 2 && *iters >= 8 && !*fail && ref_us_per_iter > 0 && !hook_force_paced) {
             if (wall / *iters > 1.3 * ref_us_per_iter) { if (++n_paced_slow >= 3) host_slow = true; } else n_paced_slow = 0;
         }
         return 0;
     }
     // (only where the structure's first solves showed a host with room to spare: on a 150-pose graph an iteration is 20 kernels at the floor, 74 us,
     // and waiting for a gate before enqueueing the next iteration would expose the host's 60 us every time: use_graphs = 0 keeps the predicted burst there)
-    bool paced() const { return amg_on && !cg_graph && !collective() && cfg.use_graphs != 1 && n_decided >= kDecideSolves && 2 * n_slow_seen <= kDecideSolves && !host_slow && !prof_on && h_flag != nullptr; }
+    bool paced() const {
+        if (!amg_on || cg_graph || collective() || cfg.use_graphs == 1 || prof_on || h_flag == nullptr) return false;
+        if (hook_force_paced) return true;       // test hook (TSGO_TESTING builds): the paced path from the first solve on
+        return n_decided >= kDecideSolves && 2 * n_slow_seen <= kDecideSolves && !host_slow;
+    }
 
     // PCG until the device state says done.  The state ring is at slot 0 on entry and on exit.
     int do_solve_once(int* iters, int* fail) {
@@ -1525,7 +1611,7 @@ template <typename T> struct Engine : IEngine {
         const int by_age = (amg_on && hier_age >= 0 && hier_age < kAgeSlots) ? iters_by_age[hier_age] : 0;
         const int pred = amg_on ? (by_age > 0 ? by_age : (hier_age == 0 && iters_fresh > 0 ? iters_fresh : predicted_cg + 1)) : predicted_cg;
         int burst = amg_on ? std::max(1, (pred + 1 + ch - 1) / ch) : std::max(1, (int)(0.9 * pred) / ch);
-        static const bool timing = getenv("TSGO_SOLVE_TIMING") != nullptr;
+        const bool timing = solve_timing;
         const auto w0 = std::chrono::steady_clock::now();
         auto since = [&] { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - w0).count(); };
         for (;;) {
@@ -1610,7 +1696,7 @@ template <typename T> struct Engine : IEngine {
         // (3 us per launch against 7 on an EPYC 9575F: eager is then 1-3 % FASTER than the replay and steadier, profiles/r03z_eager_vs_graph.txt);
         // a host that cannot keep that distance (busy cores, a slow clock, a profiler; or a graph of 10k poses, whose iteration the device runs in 99 us)
         // is noticed by do_solve_once and the handle goes over to replay.
-        if (getenv("TSGO_FORCE_HOST_SLOW")) host_slow = true;      // test hook
+        if (hook_force_host_slow) host_slow = true;      // test hook (TSGO_TESTING builds)
         const bool want_graph = cfg.use_graphs == 1 || (cfg.use_graphs == 2 && (host_slow || !amg_on));      // (block-Jacobi PCG is two short kernels per iteration, thousands of times: always replayed)
         if (want_graph && !collective() && !cg_graph && optimize_calls_on_tables >= 1) { if (int rc = capture_cg_graph()) return rc; }
         inject_armed = true;
@@ -1955,6 +2041,7 @@ int tsgo_profile_iteration(tsgo_optimizer* o, int32_t reps, tsgo_prof_entry* out
     if (!o || !out || reps <= 0 || cap <= 0) return tsgo::set_error(-1, "tsgo_profile_iteration: bad argument");
     return o->eng->profile_iteration(reps, out, cap);
 }
+#ifdef TSGO_TESTING
 int tsgo_local_group_create(int32_t world, tsgo_local_group** out) {
     if (!out || world < 1) return tsgo::set_error(-1, "tsgo_local_group_create: bad argument");
     auto* g = new tsgo_local_group(); g->world = world; g->stage.resize(world);
@@ -1967,6 +2054,10 @@ int tsgo_comm_init_local(tsgo_optimizer* o, tsgo_local_group* g) {
     if (o->cfg.world != g->world || o->cfg.rank < 0 || o->cfg.rank >= g->world) return tsgo::set_error(-1, "tsgo_comm_init_local: the handle's rank / world do not fit the group");
     o->eng->lgroup = g;
     return 0;
+}
+#endif
+void tsgo_reset_history(tsgo_optimizer* o) {
+    if (o && o->eng) o->eng->reset_history();
 }
 int tsgo_comm_selftest(tsgo_optimizer* o, int32_t* ranks_out) {
     if (!o) return tsgo::set_error(-1, "tsgo_comm_selftest: null argument");

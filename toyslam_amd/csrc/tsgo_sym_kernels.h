@@ -238,6 +238,9 @@ __global__ __launch_bounds__(kSymWave) void k_s0_count(int P, const int* __restr
         distinct += fresh; ++odn;
     }
     distinct = sym_wave_sum(distinct); pairs = sym_wave_sum(pairs); odn = sym_wave_sum(odn);
+    // the odometry neighbours count too: k_s0_fill's cols / cnt / cnt_od hold kSymMaxDistinct entries (a pose with ~1024 co-observers
+    // plus odometry or loop-closure neighbours that are not among them): the host builder takes such a graph
+    if (distinct > kSymMaxDistinct) { if (lane == 0) *overflow = 1; return; }
     if (lane == 0) { d[i] = distinct; m[i] = pairs; mo[i] = odn; }
 }
 

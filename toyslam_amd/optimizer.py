@@ -17,8 +17,12 @@ STOP = {0: "cap", 1: "worse", 2: "plateau", 3: "converged", 4: "solver_failed"}
 class HipOptimizer:
     def __init__(self, device=0, precision=64, pcg_rel_tol=1e-10, pcg_max_iters=20000, lanes_per_pose=0,
                  lanes_per_lm=0, use_graphs="auto", rank=0, world=1, preconditioner="amg", xcd_map=None, warm_start=None,
-                 reuse_structure=None, rules="cpp", lr=0.2, odom_jacobian="constant", cycle_level0="implicit", cycle_storage=16, warm_requests=False):
-        self.lib = _lib.hip_lib()
+                 reuse_structure=None, rules="cpp", lr=0.2, odom_jacobian="constant", cycle_level0="implicit", cycle_storage=16, warm_requests=False, testing=False):
+        # testing=True: libtsgo_hip_testing.so (the same sources with -DTSGO_TESTING: hooks, research variables, in-process group)
+        # (TSGO_PY_TESTING_LIB=1: research scripts under tools/research and tests/research that set hook / research variables pick the
+        # testing library without being edited; it selects which LIBRARY this Python wrapper loads, the product library reads nothing)
+        import os
+        self.lib = _lib.hip_testing_lib() if (testing or os.environ.get("TSGO_PY_TESTING_LIB") == "1") else _lib.hip_lib()
         cfg = _lib.tsgo_config()
         self.lib.tsgo_default_config(C.byref(cfg))
         cfg.device, cfg.precision, cfg.pcg_rel_tol, cfg.pcg_max_iters = device, precision, pcg_rel_tol, pcg_max_iters
@@ -69,6 +73,10 @@ class HipOptimizer:
         _lib.check(self.lib, self.lib.tsgo_set_graph(self.h, C.byref(cg)), "tsgo_set_graph")
         self.n_vertices = len(g.v_id)
         self._v_in = g.v_pos.copy() if self.cfg.world > 1 else None    # a shard returns its own landmarks; the others keep their input
+
+    def reset_history(self):
+        """warm_requests: the next set_graph starts the solver from nothing (a pooled handle changing hands)."""
+        self.lib.tsgo_reset_history(self.h)
 
     def optimize(self, iterations):
         st = _lib.tsgo_stats()
@@ -139,15 +147,15 @@ class HipOptimizer:
 
 
 def local_group(world):
-    """An in-process all-reduce group for `world` HipOptimizer handles (tests of the sharded path on a one-GPU box)."""
-    lib = _lib.hip_lib()
+    """An in-process all-reduce group for `world` HipOptimizer(testing=True) handles (tests of the sharded path on a one-GPU box)."""
+    lib = _lib.hip_testing_lib()
     g = C.c_void_p()
     _lib.check(lib, lib.tsgo_local_group_create(world, C.byref(g)), "tsgo_local_group_create")
     return g
 
 
 def free_local_group(group):
-    _lib.hip_lib().tsgo_local_group_destroy(group)
+    _lib.hip_testing_lib().tsgo_local_group_destroy(group)
 
 
 class GraphOptimizer:

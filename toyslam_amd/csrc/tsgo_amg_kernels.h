@@ -636,7 +636,7 @@ __global__ __launch_bounds__(256) void k_small_gemm(int M, int N, int K, const T
 // entry and its mirror are both evaluated by the thread (and again, in the other order, by the mirror's thread: a + b == b + a).
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_bottom_finish(int n3, const T* __restrict__ Sd, const HT<T>* __restrict__ Dinv, const T* __restrict__ omega_ptr,
-                                                          const T* __restrict__ Bd, float* __restrict__ Bf) {
+                                                          const T* __restrict__ Bd, float* __restrict__ Bf, T* __restrict__ Bs) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= n3 * n3) return;
     const int r = t / n3, c = t % n3;
@@ -649,24 +649,181 @@ __global__ __launch_bounds__(kBlock) void k_bottom_finish(int n3, const T* __res
         if (rr / 3 == jb) v += w * T(Dinv[(size_t)jb * 9 + 3 * (rr % 3) + y]);
         return v;
     };
-    Bf[(size_t)r * n3 + c] = (float)(T(0.5) * (entry(r, c) + entry(c, r)));
+    const T v = T(0.5) * (entry(r, c) + entry(c, r));
+    Bf[(size_t)r * n3 + c] = (float)v;
+    if (Bs) Bs[(size_t)r * n3 + c] = v;
 }
 
-// z = B r, one wavefront per row (n3 <= 768 rows: every row is one coalesced pass), the level's whole cycle in one launch
+// z = B r for a dense f32 matrix B [n_rows x n_cols], one wavefront per row (every row a few coalesced passes): the last level's
+// whole cycle in one launch (B = the level's operator), or t = E^T r of the level above it (B = E^T, below)
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_bottom_apply(int n3, const float* __restrict__ Bf, const T* __restrict__ r, T* __restrict__ z, const CgState<T>* __restrict__ st) {
+__global__ __launch_bounds__(kBlock) void k_bottom_apply(int n_rows, int n_cols, const float* __restrict__ Bf, const T* __restrict__ r, T* __restrict__ z, const CgState<T>* __restrict__ st) {
     const int done = st->done;
     const int row = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
-    const int rc = row < n3 ? row : n3 - 1;
-    const float* b = Bf + (size_t)rc * n3;
+    const int rc = row < n_rows ? row : n_rows - 1;
+    const float* b = Bf + (size_t)rc * n_cols;
     T acc = 0;
-    float b0 = lane < n3 ? b[lane] : 0.f;
+    float b0 = lane < n_cols ? b[lane] : 0.f;
     issue_before_exit(b0);
     if (done) return;
-    if (lane < n3) acc = T(b0) * r[lane];
-    for (int c = lane + 64; c < n3; c += 64) acc += T(b[c]) * r[c];
+    if (lane < n_cols) acc = T(b0) * r[lane];
+    for (int c = lane + 64; c < n_cols; c += 64) acc += T(b[c]) * r[c];
     acc = wave_sum<T>(acc);
-    if (row < n3 && lane == 0) z[row] = acc;
+    if (row < n_rows && lane == 0) z[row] = acc;
+}
+
+// ---- ... and the level ABOVE it in factored form -----------------------------------------------------------------------------------
+// With B_b the dense operator of the bottom level b, the V(1,1) cycle of the level q above it is the linear map
+//     z = W r + S W r + E B_b E^T r,      W = omega D^-1,  S = I - W A,  E = S P            (q's own W, A, P)
+// and with z1 = W r (the pre-sweep the restriction INTO q already leaves) and t = E^T r it is applied as
+//     z = 2 z1 - W (A z1) + G t,          G = E B_b    (dense [3 n_q x 3 n_b], formed once per hierarchy build)
+// — two launches (t = E^T r: k_bottom_apply on E^T;  k_tail_up) for what was residual, restrict, the bottom's cycle, prolong and
+// post-sweep: five launches with B_b, seven before it.  E = P - W (A P) needs no pattern of A P: the level's block rows times dense P.
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_scatter_blocks(int nnz, const int* __restrict__ row, const int* __restrict__ col, const HT<T>* __restrict__ blk, int ld, T* __restrict__ out) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= nnz) return;
+    const int i = row[b], c = col[b];
+#pragma unroll
+    for (int x = 0; x < 3; ++x)
+#pragma unroll
+        for (int y = 0; y < 3; ++y) out[(size_t)(3 * i + x) * ld + 3 * c + y] = T(blk[(size_t)b * 9 + 3 * x + y]);
+}
+
+// E -= omega D^-1 T over the blocks of T = A P (computed by the Galerkin setup: Tv), E holding the scattered P on entry; one wavefront
+// per block row, a lane per block of the row
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_tail_E(int n, const int* __restrict__ tptr, const int* __restrict__ tcol, const HT<T>* __restrict__ Tv, const HT<T>* __restrict__ Dinv,
+                                                   const T* __restrict__ omega_ptr, int nd, T* __restrict__ E) {
+    const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+    if (i >= n) return;
+    const T w = *omega_ptr;
+    T d[9];
+#pragma unroll
+    for (int m = 0; m < 9; ++m) d[m] = T(Dinv[(size_t)i * 9 + m]);
+    for (int tb = tptr[i] + lane; tb < tptr[i + 1]; tb += 64) {
+        const int c = tcol[tb];
+        T t[9], o[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int m = 0; m < 9; ++m) t[m] = T(Tv[(size_t)tb * 9 + m]);
+        m3_mul_acc<T>(d, t, o);
+#pragma unroll
+        for (int x = 0; x < 3; ++x)
+#pragma unroll
+            for (int y = 0; y < 3; ++y) E[(size_t)(3 * i + x) * nd + 3 * c + y] -= w * o[3 * x + y];
+    }
+}
+
+// C[M x N] = A[M x K] B[K x N], row-major: 64 x 64 tile per workgroup, 4 x 4 outputs per thread, K in steps of 16 through LDS
+template <typename T>
+__global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, T* __restrict__ C, int ldc) {
+    __shared__ T sa[16][65], sb[16][65];
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
+    T acc[4][4] = {};
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        // A tile 64 x 16: thread loads 4 entries; B tile 16 x 64: 4 entries
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int e = threadIdx.x + 256 * q;
+            const int ar = e >> 4, ak = e & 15;                   // A: row ar (0..63), k ak (0..15): consecutive threads walk k
+            sa[ak][ar] = (row0 + ar < M && k0 + ak < K) ? A[(size_t)(row0 + ar) * lda + k0 + ak] : T(0);
+            const int bk = e >> 6, bc = e & 63;                   // B: k bk (0..15), col bc (0..63): consecutive threads walk the columns
+            sb[bk][bc] = (k0 + bk < K && col0 + bc < N) ? B[(size_t)(k0 + bk) * ldb + col0 + bc] : T(0);
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            T a[4], b[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) { a[u] = sa[k][ty * 4 + u]; b[u] = sb[k][tx * 4 + u]; }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int v = 0; v < 4; ++v) {
+            const int r = row0 + ty * 4 + u, c = col0 + tx * 4 + v;
+            if (r < M && c < N) C[(size_t)r * ldc + c] = acc[u][v];
+        }
+}
+
+// the run-time copies: Etf = f32(E^T) [nd x n3], Gf = f32(G) [n3 x nd]
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_tail_pack(int n3, int nd, const T* __restrict__ E, const T* __restrict__ G, float* __restrict__ Etf, float* __restrict__ Gf) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= n3 * nd) return;
+    const int i = t / nd, m = t % nd;
+    Gf[t] = (float)G[t];
+    Etf[(size_t)m * n3 + i] = (float)E[t];
+}
+
+// z = B r for a dense f32 matrix with LONG rows (n_cols in the thousands): one workgroup per row, every load of a thread issued
+// before its first use, block reduction.  (One wavefront per row, k_bottom_apply, walks such a row in 43 dependent trips: 21 us.)
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_rowdot_wg(int n_rows, int n_cols, const float* __restrict__ Bf, const T* __restrict__ r, T* __restrict__ z, const CgState<T>* __restrict__ st) {
+    __shared__ T red[kWavesPerBlock];
+    const int done = st->done;
+    const int row = blockIdx.x;
+    const float* b = Bf + (size_t)row * n_cols;
+    constexpr int U = 4;
+    T acc = 0;
+    float b0 = (int)threadIdx.x < n_cols ? b[threadIdx.x] : 0.f;
+    issue_before_exit(b0);
+    if (done) return;                                        // workgroup-uniform
+    for (int c0 = threadIdx.x; c0 < n_cols; c0 += U * kBlock) {
+        float bv[U]; T rv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) { const int c = c0 + u * kBlock; const bool in = c < n_cols; bv[u] = in ? b[c] : 0.f; rv[u] = in ? r[c] : T(0); }
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc += T(bv[u]) * rv[u];
+    }
+    const T total = block_sum<T>(acc, red);
+    if (threadIdx.x == 0) z[row] = total;
+}
+
+// z_i = 2 z1_i - omega D_i^-1 sum_j A_ij z1_j + sum_m G[3i..3i+2][m] t[m]: one WORKGROUP per block row (A in the cycle format): the
+// row's blocks a lane each, the three dense rows of G spread over all 256 threads
+template <typename T, int PK>
+__global__ __launch_bounds__(kBlock) void k_tail_up(int n, const int* __restrict__ ptr, const int* __restrict__ col, const uint32_t* __restrict__ Apm, const HT<T>* __restrict__ Dinv,
+                                                    const T* __restrict__ omega_ptr, const T* __restrict__ z1, int nd, const float* __restrict__ Gf, const T* __restrict__ t,
+                                                    T* __restrict__ z, const CgState<T>* __restrict__ st) {
+    __shared__ T red[kWavesPerBlock];
+    const int done = st->done;
+    const int i = blockIdx.x;
+    int p0 = ptr[i];
+    const int p1 = ptr[i + 1];
+    issue_before_exit(p0);
+    if (done) return;                                        // workgroup-uniform
+    // the dense part first: its operands depend on the arguments alone
+    const float* g0 = Gf + (size_t)i * 3 * nd;
+    T d0 = 0, d1 = 0, d2 = 0;
+    for (int m = threadIdx.x; m < nd; m += kBlock) { const T tm = t[m]; d0 += T(g0[m]) * tm; d1 += T(g0[nd + m]) * tm; d2 += T(g0[2 * (size_t)nd + m]) * tm; }
+    T s0 = 0, s1 = 0, s2 = 0;
+    const size_t len = (size_t)(p1 - p0);
+    const uint32_t* base = Apm + (size_t)p0 * cy_words<PK>();
+    for (int a = p0 + threadIdx.x; a < p1; a += kBlock) {
+        const T* v = z1 + (size_t)col[a] * 3;
+        T b[9];
+        cy_load<T, PK>(base, len, (size_t)(a - p0), b);
+        const T v0 = v[0], v1 = v[1], v2 = v[2];
+        s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
+    }
+    s0 = block_sum<T>(s0, red); s1 = block_sum<T>(s1, red); s2 = block_sum<T>(s2, red);
+    d0 = block_sum<T>(d0, red); d1 = block_sum<T>(d1, red); d2 = block_sum<T>(d2, red);
+    if (threadIdx.x == 0) {
+        const T w = *omega_ptr;
+        const HT<T>* d = Dinv + (size_t)i * 9;
+        const T* zi = z1 + (size_t)i * 3;
+        z[(size_t)i * 3] = T(2) * zi[0] - w * (T(d[0]) * s0 + T(d[1]) * s1 + T(d[2]) * s2) + d0;
+        z[(size_t)i * 3 + 1] = T(2) * zi[1] - w * (T(d[3]) * s0 + T(d[4]) * s1 + T(d[5]) * s2) + d1;
+        z[(size_t)i * 3 + 2] = T(2) * zi[2] - w * (T(d[6]) * s0 + T(d[7]) * s1 + T(d[8]) * s2) + d2;
+    }
 }
 
 // coarsest level alone (graphs with a single explicit level): z = inv r, single workgroup

@@ -182,6 +182,7 @@ template <typename T> struct DevLevel {      // device copy of one AmgLevel (hos
     int *R_ptr = nullptr, *R_col = nullptr, *r_to_p = nullptr, *p_to_r = nullptr;
     int *ts_ptr = nullptr, *ts_x = nullptr, *ts_y = nullptr, *as_ptr = nullptr, *as_x = nullptr, *as_y = nullptr, *as_mirror = nullptr, *as_upper = nullptr;
     int n_upper = 0;
+    int *T_ptr = nullptr, *T_col = nullptr;      // pattern of T = A P (the factored dense level reads it: E = P - W T)
     bool patterns_up = false;      // A / P / R patterns are on the device already (the device built this level's pair-list products)
     bool products_dev = false;     // ts_* / as_* were built on the device (tsgo_sym_kernels.h): nothing of them exists on the host
     using H = HT<T>;                              // hierarchy storage type (tsgo_amg_kernels.h)
@@ -464,7 +465,7 @@ template <typename T> struct Engine : IEngine {
         if (!D.products_dev) {       // the host built the two pair-list products (sharded runs, TSGO_HOST_PRODUCTS, a row too dense for the device tables)
             D.nnzT = L.T.nnz(); D.nnzNext = (int)L.a_src.ptr.size() - 1;
             D.pairs_T = (double)L.t_src.x.size() / std::max(1, D.nnzT); D.pairs_A = (double)L.a_src.x.size() / std::max<double>(1, (double)std::count(L.a_mirror.begin(), L.a_mirror.end(), -1));
-            UP(D.ts_ptr, L.t_src.ptr); UP(D.ts_x, L.t_src.x); UP(D.ts_y, L.t_src.y);
+            UP(D.ts_ptr, L.t_src.ptr); UP(D.ts_x, L.t_src.x); UP(D.ts_y, L.t_src.y); UP(D.T_ptr, L.T.ptr); UP(D.T_col, L.T.col);
             UP(D.as_ptr, L.a_src.ptr); UP(D.as_x, L.a_src.x); UP(D.as_y, L.a_src.y); UP(D.as_mirror, L.a_mirror);
             { std::vector<int> up; for (int b = 0; b < (int)L.a_mirror.size(); ++b) if (L.a_mirror[b] < 0) up.push_back(b); D.n_upper = (int)up.size(); UP(D.as_upper, up); }
         }
@@ -618,7 +619,7 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipMemcpyAsync(&h3[1], flags + 2, sizeof(int), hipMemcpyDeviceToHost, cs()));
         HIP_OK(hipStreamSynchronize(cs()));
         if (h3[1]) return set_error(-2, "tsgo_set_graph: the Galerkin pattern is not structurally symmetric");
-        D.n_upper = h3[0]; D.nnzT = nnzT; D.nnzNext = nnzN;
+        D.n_upper = h3[0]; D.nnzT = nnzT; D.nnzNext = nnzN; D.T_ptr = tptr; D.T_col = tcol;
         D.pairs_T = (double)pairsT / std::max(1, nnzT); D.pairs_A = (double)pairsA / std::max(1, D.n_upper);
         D.products_dev = true;
         *accepted = true;
@@ -662,35 +663,61 @@ template <typename T> struct Engine : IEngine {
         HIP_OK(hipHostMalloc((void**)&h_rho, sizeof(T) * 16 * 2 * kRhoBlocks));
         lin_count = 0; hier_age = -1;
         // the bottom of the cycle as one dense operator (tsgo_amg_kernels.h: k_bottom_*): the last explicit level when it is small enough
-        bottom_dense = lv.size() >= 2 && lv.back().n * 4 <= kDenseThreads && nb_last > 0;
+        // and runs V(1,1); and the level above it in factored form (k_tail_*) when that one is small too
+        const size_t nl = lv.size();
+        bottom_dense = nl >= 2 && lv.back().n * 4 <= kDenseThreads && nb_last > 0 && nu_at(nl - 1) == 1;
+        tail2 = bottom_dense && nl >= 3 && lv[nl - 2].n <= kSmallLevelRows && nu_at(nl - 2) == 1 && (size_t)lv[nl - 2].n * 3 * (size_t)lv.back().n * 3 <= (size_t(4) << 20);
         if (bottom_dense) {
             const size_t n3 = (size_t)lv.back().n * 3, nd = (size_t)nb_last * 3;
             if (int rc = dalloc(&bot_S, n3 * n3)) return rc;
             if (int rc = dalloc(&bot_B, n3 * n3)) return rc;
+            if (int rc = dalloc(&bot_Bs, n3 * n3)) return rc;
             if (int rc = dalloc(&bot_P, n3 * nd)) return rc;
             if (int rc = dalloc(&bot_E, n3 * nd)) return rc;
             if (int rc = dalloc(&bot_F, n3 * nd)) return rc;
             if (int rc = dalloc(&bot_Bf, n3 * n3)) return rc;
         }
+        if (tail2) {
+            const size_t n3 = (size_t)lv[nl - 2].n * 3, nd = (size_t)lv.back().n * 3;
+            if (int rc = dalloc(&tail_E, n3 * nd)) return rc;
+            if (int rc = dalloc(&tail_G, n3 * nd)) return rc;
+            if (int rc = dalloc(&tail_Etf, n3 * nd)) return rc;
+            if (int rc = dalloc(&tail_Gf, n3 * nd)) return rc;
+            if (int rc = dalloc(&tail_t, nd)) return rc;
+        }
         return 0;
     }
-    bool bottom_dense = false;
-    T *bot_S = nullptr, *bot_B = nullptr, *bot_P = nullptr, *bot_E = nullptr, *bot_F = nullptr; float* bot_Bf = nullptr;
-    // B = W + S W + E C E^T of the last explicit level (after k_dense_inverse, and again whenever the level's damping changes)
+    bool bottom_dense = false, tail2 = false;
+    T *bot_S = nullptr, *bot_B = nullptr, *bot_Bs = nullptr, *bot_P = nullptr, *bot_E = nullptr, *bot_F = nullptr; float* bot_Bf = nullptr;
+    T *tail_E = nullptr, *tail_G = nullptr, *tail_t = nullptr; float *tail_Etf = nullptr, *tail_Gf = nullptr;
+    // B = W + S W + E C E^T of the last explicit level (after k_dense_inverse, and again whenever the level's damping changes), then
+    // E = P - W (A P) and G = E B of the level above it
     int launch_bottom_setup() {
         if (!bottom_dense) return 0;
-        DevLevel<T>& L = lv.back();
-        const int n3 = L.n * 3, nd = nb_last * 3;
-        const T* om = omega_dev + (lv.size() - 1);
-        HIP_OK(hipMemsetAsync(bot_S, 0, sizeof(T) * (size_t)n3 * n3, stream));
-        HIP_OK(hipMemsetAsync(bot_P, 0, sizeof(T) * (size_t)n3 * nd, stream));
-        hipLaunchKernelGGL((k_bottom_scatter<T>), dim3(grid_for(L.nnzA + L.nnzP)), dim3(kBlock), 0, stream, L.nnzA, (const int*)L.A_row, (const int*)L.A_col, (const H*)L.A, (const H*)L.Dinv, om,
-                           L.nnzP, (const int*)L.P_row, (const int*)L.P_col, (const H*)L.P, n3, nd, bot_S, bot_P);
         auto tiles = [](int n) { return (unsigned)((n + 15) / 16); };
-        hipLaunchKernelGGL((k_small_gemm<T, 0>), dim3(tiles(nd), tiles(n3)), dim3(256), 0, stream, n3, nd, n3, (const T*)bot_S, n3, (const T*)bot_P, nd, bot_E, nd);          // E = S P
-        hipLaunchKernelGGL((k_small_gemm<T, 0>), dim3(tiles(nd), tiles(n3)), dim3(256), 0, stream, n3, nd, nd, (const T*)bot_E, nd, (const T*)inv_last, nd, bot_F, nd);      // F = E C
-        hipLaunchKernelGGL((k_small_gemm<T, 1>), dim3(tiles(n3), tiles(n3)), dim3(256), 0, stream, n3, n3, nd, (const T*)bot_F, nd, (const T*)bot_E, nd, bot_B, n3);         // G = F E^T
-        hipLaunchKernelGGL((k_bottom_finish<T>), dim3(grid_for(n3 * n3)), dim3(kBlock), 0, stream, n3, (const T*)bot_S, (const H*)L.Dinv, om, (const T*)bot_B, bot_Bf);
+        {
+            DevLevel<T>& L = lv.back();
+            const int n3 = L.n * 3, nd = nb_last * 3;
+            const T* om = omega_dev + (lv.size() - 1);
+            HIP_OK(hipMemsetAsync(bot_S, 0, sizeof(T) * (size_t)n3 * n3, stream));
+            HIP_OK(hipMemsetAsync(bot_P, 0, sizeof(T) * (size_t)n3 * nd, stream));
+            hipLaunchKernelGGL((k_bottom_scatter<T>), dim3(grid_for(L.nnzA + L.nnzP)), dim3(kBlock), 0, stream, L.nnzA, (const int*)L.A_row, (const int*)L.A_col, (const H*)L.A, (const H*)L.Dinv, om,
+                               L.nnzP, (const int*)L.P_row, (const int*)L.P_col, (const H*)L.P, n3, nd, bot_S, bot_P);
+            hipLaunchKernelGGL((k_small_gemm<T, 0>), dim3(tiles(nd), tiles(n3)), dim3(256), 0, stream, n3, nd, n3, (const T*)bot_S, n3, (const T*)bot_P, nd, bot_E, nd);          // E = S P
+            hipLaunchKernelGGL((k_small_gemm<T, 0>), dim3(tiles(nd), tiles(n3)), dim3(256), 0, stream, n3, nd, nd, (const T*)bot_E, nd, (const T*)inv_last, nd, bot_F, nd);      // F = E C
+            hipLaunchKernelGGL((k_small_gemm<T, 1>), dim3(tiles(n3), tiles(n3)), dim3(256), 0, stream, n3, n3, nd, (const T*)bot_F, nd, (const T*)bot_E, nd, bot_B, n3);         // G = F E^T
+            hipLaunchKernelGGL((k_bottom_finish<T>), dim3(grid_for(n3 * n3)), dim3(kBlock), 0, stream, n3, (const T*)bot_S, (const H*)L.Dinv, om, (const T*)bot_B, bot_Bf, bot_Bs);
+        }
+        if (tail2) {
+            DevLevel<T>& L = lv[lv.size() - 2];
+            const int n3 = L.n * 3, nd = lv.back().n * 3;
+            const T* om = omega_dev + (lv.size() - 2);
+            HIP_OK(hipMemsetAsync(tail_E, 0, sizeof(T) * (size_t)n3 * nd, stream));
+            hipLaunchKernelGGL((k_scatter_blocks<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, (const int*)L.P_row, (const int*)L.P_col, (const H*)L.P, nd, tail_E);
+            hipLaunchKernelGGL((k_tail_E<T>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, (const int*)L.T_ptr, (const int*)L.T_col, (const H*)L.Tv, (const H*)L.Dinv, om, nd, tail_E);      // E = P - W (A P)
+            hipLaunchKernelGGL((k_gemm64<T>), dim3((nd + 63) / 64, (n3 + 63) / 64), dim3(256), 0, stream, n3, nd, nd, (const T*)tail_E, nd, (const T*)bot_Bs, nd, tail_G, nd);      // G = E B
+            hipLaunchKernelGGL((k_tail_pack<T>), dim3(grid_for(n3 * nd)), dim3(kBlock), 0, stream, n3, nd, (const T*)tail_E, (const T*)tail_G, tail_Etf, tail_Gf);
+        }
         return 0;
     }
 #undef UP
@@ -1226,14 +1253,15 @@ template <typename T> struct Engine : IEngine {
             DevLevel<T>& L = lv[0];
             const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
             if (nl > 1) PF(bytes_transfer(L, 2), "restrict from L0", "k_restrict<%s, %d, 1, %d>", tname(), lpr, cy16 ? 1 : 0);
-            if (nl > 1) launch_restrict<1>(lpr, L, (const T*)r, (const T*)sbuf, lv[1].r, (bottom_dense && nl == 2) ? (const H*)nullptr : (const H*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);
+            if (nl > 1) launch_restrict<1>(lpr, L, (const T*)r, (const T*)sbuf, lv[1].r, (bottom_dense && nl == 2) ? (const H*)nullptr : (const H*)lv[1].Dinv, lv[1].z, (const T*)(omega_dev + 1), s);      // (nl == 3 with the factored level: lv[1] keeps its pre-sweep)
         }
         // coarse levels: V(nu,nu) with nu = coarse_sweeps block-Jacobi sweeps (the first pre-sweep comes fused
         // with the restriction above).  The current iterate alternates between L.z and L.z2; it ends in L.z2.
-        const bool dense_bottom = bottom_dense && nl > 1;      // the last explicit level's whole cycle is one dense product (k_bottom_apply)
-        for (size_t l = 1; l < nl; ++l) {
+        const bool dense_bottom = bottom_dense && nl > 1;      // the last explicit level's whole cycle is one dense product (k_bottom_apply) ...
+        const bool dense_tail2 = dense_bottom && tail2;        // ... and the level above it two launches (t = E^T r, k_tail_up)
+        const size_t first_dense = dense_tail2 ? nl - 2 : (dense_bottom ? nl - 1 : nl);      // levels from here down run no sweeps of their own
+        for (size_t l = 1; l < std::min(nl, first_dense); ++l) {
             DevLevel<T>& L = lv[l];
-            if (dense_bottom && l + 1 == nl) break;
             const int nu = nu_at(l);
             const int lprA = lanes_for_sweep((double)L.nnzA / std::max(1, L.n), L.n);
             T* cur = L.z; T* oth = L.z2;
@@ -1246,19 +1274,27 @@ template <typename T> struct Engine : IEngine {
             launch_sweep<0>(lprA, L, (const T*)L.r, (const T*)cur, L.res, (const T*)(omega_dev + l), s);
             if (l + 1 < nl) {
                 const int lpr = lanes_for((double)L.nnzP / std::max(1, L.n_agg));
-                const bool into_dense = dense_bottom && l + 2 == nl;      // the dense operator pre-smooths by itself
+                const bool no_presmooth = dense_bottom && !dense_tail2 && l + 2 == nl;      // the dense bottom operator pre-smooths by itself (the factored level wants z1 = W r)
                 PF(bytes_transfer(L, 1), lvl("restrict from", l).c_str(), "k_restrict<%s, %d, 0, %d>", tname(), lpr, cy16 ? 1 : 0);
-                launch_restrict<0>(lpr, L, (const T*)L.res, (const T*)L.res, lv[l + 1].r, into_dense ? (const H*)nullptr : (const H*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
+                launch_restrict<0>(lpr, L, (const T*)L.res, (const T*)L.res, lv[l + 1].r, no_presmooth ? (const H*)nullptr : (const H*)lv[l + 1].Dinv, lv[l + 1].z, (const T*)(omega_dev + l + 1), s);
             }
         }
         // iterate of level l after the down pass: L.z when nu is odd, L.z2 when even
         auto down_iter = [&](DevLevel<T>& L, int nu) { return (nu % 2) ? L.z : L.z2; };
         auto down_other = [&](DevLevel<T>& L, int nu) { return (nu % 2) ? L.z2 : L.z; };
-        if (dense_bottom) {      // z2 = B r: pre-sweep, coarse correction through the dense inverse and post-sweep of the last explicit level at once
+        if (dense_tail2) {       // levels nl-2 and nl-1 at once: z2 = 2 z1 - W A z1 + G (E^T r), z1 = W r left by the restriction into nl-2
+            DevLevel<T>& L = lv[nl - 2];
+            const int n3 = L.n * 3, nd = lv[nl - 1].n * 3;
+            PF((double)n3 * nd * sizeof(float) + (double)(n3 + nd) * sizeof(T), lvl("t = E^T r of", nl - 2).c_str(), "k_rowdot_wg<%s>", tname());
+            hipLaunchKernelGGL((k_rowdot_wg<T>), dim3(nd), dim3(kBlock), 0, stream, nd, n3, (const float*)tail_Etf, (const T*)L.r, tail_t, s);
+            PF(bytes_sweep(L) + (double)n3 * nd * sizeof(float), lvl("cycles of", nl - 2).c_str(), "k_tail_up<%s, %d>", tname(), cy16 ? 1 : 0);
+            if (cy16) hipLaunchKernelGGL((k_tail_up<T, 1>), dim3(L.n), dim3(kBlock), 0, stream, L.n, (const int*)L.A_ptr, (const int*)L.A_col, (const uint32_t*)L.Apm, (const H*)L.Dinv, (const T*)(omega_dev + nl - 2), (const T*)L.z, nd, (const float*)tail_Gf, (const T*)tail_t, L.z2, s);
+            else hipLaunchKernelGGL((k_tail_up<T, 0>), dim3(L.n), dim3(kBlock), 0, stream, L.n, (const int*)L.A_ptr, (const int*)L.A_col, (const uint32_t*)L.Apm, (const H*)L.Dinv, (const T*)(omega_dev + nl - 2), (const T*)L.z, nd, (const float*)tail_Gf, (const T*)tail_t, L.z2, s);
+        } else if (dense_bottom) {      // z2 = B r: pre-sweep, coarse correction through the dense inverse and post-sweep of the last explicit level at once
             DevLevel<T>& L = lv[nl - 1];
             const int n3 = L.n * 3;
             PF((double)n3 * n3 * sizeof(float) + 2.0 * n3 * sizeof(T), lvl("whole cycle of", nl - 1).c_str(), "k_bottom_apply<%s>", tname());
-            hipLaunchKernelGGL((k_bottom_apply<T>), dim3(grid_for(n3, 64)), dim3(kBlock), 0, stream, n3, (const float*)bot_Bf, (const T*)L.r, L.z2, s);
+            hipLaunchKernelGGL((k_bottom_apply<T>), dim3(grid_for(n3, 64)), dim3(kBlock), 0, stream, n3, n3, (const float*)bot_Bf, (const T*)L.r, L.z2, s);
         } else if (nl > 1 && lv[nl - 1].n * 4 <= kDenseThreads) {   // bottom: restrict + dense inverse + prolong in one workgroup, on the last explicit level
             DevLevel<T>& L = lv[nl - 1];
             PF(2.0 * L.nnzP * (9 * sizeof(H) + 4) + (double)nb_last * 3 * nb_last * 3 * sizeof(T) + L.n * 6.0 * sizeof(T), lvl("restrict + dense solve + prolong", nl - 1).c_str(), "k_coarse_tail<%s>", tname());
@@ -1280,7 +1316,7 @@ template <typename T> struct Engine : IEngine {
         }
         for (size_t l = nl - 1; l >= 1; --l) {
             DevLevel<T>& L = lv[l];
-            if (dense_bottom && l + 1 == nl) continue;      // its result is in L.z2 already
+            if (l >= first_dense) continue;      // a dense level's result is in its z2 already
             const int nu = nu_at(l);
             T* cur = down_iter(L, nu); T* oth = down_other(L, nu);
             if (l + 1 < nl) launch_prolong(L, lv[l + 1].z2, cur, 3, s, l);

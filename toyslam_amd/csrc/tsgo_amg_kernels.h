@@ -49,7 +49,7 @@ template <typename T> __device__ __forceinline__ void m3_inv(const T* m, T* o) {
 }
 
 // ---- numeric setup ---------------------------------------------------------------------------------
-// Explicit Schur complement blocks S_ik (level 0 of the hierarchy), one thread per block.
+// Explicit Schur complement blocks S_ik (level 0 of the hierarchy), one thread per block on or above the diagonal.
 //   diagonal: Dp - Sd from the linearisation partials; off-diagonal: -sum_j W_ij N_j W_kj^T - odom.
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __restrict__ blk_row, const int* __restrict__ blk_col,
@@ -58,9 +58,10 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
                                                          const uint32_t* __restrict__ oslot, Table<T> tb, const T* __restrict__ od_dyn,
                                                          size_t od_slots, const T* __restrict__ lmrec, const T* __restrict__ ps,
                                                          const T* __restrict__ part, HT<T>* __restrict__ A, int diag_on,
-                                                         const uint32_t* __restrict__ od_idx, int odom_analytic) {
-    const int b = blockIdx.x * kBlock + threadIdx.x;
-    if (b >= nnz) return;
+                                                         const uint32_t* __restrict__ od_idx, int odom_analytic, const int* __restrict__ which) {
+    const int t = blockIdx.x * kBlock + threadIdx.x;
+    if (t >= nnz) return;
+    const int b = which ? which[t] : t;      // which: the blocks on or above the diagonal (S is symmetric: the others are mirrored, k_mirror_blocks)
     const int i = blk_row[b], k = blk_col[b];
     HT<T>* o = A + (size_t)b * 9;
     if (i == k) {
@@ -680,21 +681,21 @@ __global__ __launch_bounds__(kBlock) void k_bottom_apply(int n_rows, int n_cols,
 // — two launches (t = E^T r: k_bottom_apply on E^T;  k_tail_up) for what was residual, restrict, the bottom's cycle, prolong and
 // post-sweep: five launches with B_b, seven before it.  E = P - W (A P) needs no pattern of A P: the level's block rows times dense P.
 template <typename T>
-__global__ __launch_bounds__(kBlock) void k_scatter_blocks(int nnz, const int* __restrict__ row, const int* __restrict__ col, const HT<T>* __restrict__ blk, int ld, T* __restrict__ out) {
+__global__ __launch_bounds__(kBlock) void k_scatter_blocks(int nnz, const int* __restrict__ row, const int* __restrict__ col, const HT<T>* __restrict__ blk, int ld, float* __restrict__ out) {
     const int b = blockIdx.x * kBlock + threadIdx.x;
     if (b >= nnz) return;
     const int i = row[b], c = col[b];
 #pragma unroll
     for (int x = 0; x < 3; ++x)
 #pragma unroll
-        for (int y = 0; y < 3; ++y) out[(size_t)(3 * i + x) * ld + 3 * c + y] = T(blk[(size_t)b * 9 + 3 * x + y]);
+        for (int y = 0; y < 3; ++y) out[(size_t)(3 * i + x) * ld + 3 * c + y] = (float)blk[(size_t)b * 9 + 3 * x + y];
 }
 
 // E -= omega D^-1 T over the blocks of T = A P (computed by the Galerkin setup: Tv), E holding the scattered P on entry; one wavefront
 // per block row, a lane per block of the row
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_tail_E(int n, const int* __restrict__ tptr, const int* __restrict__ tcol, const HT<T>* __restrict__ Tv, const HT<T>* __restrict__ Dinv,
-                                                   const T* __restrict__ omega_ptr, int nd, T* __restrict__ E) {
+                                                   const T* __restrict__ omega_ptr, int nd, float* __restrict__ E) {
     const int i = (blockIdx.x * kBlock + threadIdx.x) >> 6, lane = threadIdx.x & 63;
     if (i >= n) return;
     const T w = *omega_ptr;
@@ -710,57 +711,59 @@ __global__ __launch_bounds__(kBlock) void k_tail_E(int n, const int* __restrict_
 #pragma unroll
         for (int x = 0; x < 3; ++x)
 #pragma unroll
-            for (int y = 0; y < 3; ++y) E[(size_t)(3 * i + x) * nd + 3 * c + y] -= w * o[3 * x + y];
+            for (int y = 0; y < 3; ++y) { float* e = E + (size_t)(3 * i + x) * nd + 3 * c + y; *e = (float)(T(*e) - w * o[3 * x + y]); }
     }
 }
 
-// C[M x N] = A[M x K] B[K x N], row-major: 64 x 64 tile per workgroup, 4 x 4 outputs per thread, K in steps of 16 through LDS
-template <typename T>
-__global__ __launch_bounds__(256) void k_gemm64(int M, int N, int K, const T* __restrict__ A, int lda, const T* __restrict__ B, int ldb, T* __restrict__ C, int ldc) {
-    __shared__ T sa[16][65], sb[16][65];
+// C[M x N] = A[M x K] B[K x N], row-major f32: 32 x 64 tile per workgroup (2 x 4 outputs per thread), K in steps of 16 through LDS, the
+// next step's operands in registers while this one is multiplied.  G = E B of the factored level: 2733 x 366 x 366 at 100k poses
+// (516 workgroups); the f64 64 x 64 version without the prefetch took 115 us, a tenth of a hierarchy build.
+__global__ __launch_bounds__(256) void k_gemm_f32(int M, int N, int K, const float* __restrict__ A, int lda, const float* __restrict__ B, int ldb, float* __restrict__ C, int ldc) {
+    __shared__ float sa[16][33], sb[16][65];
     const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
-    const int row0 = blockIdx.y * 64, col0 = blockIdx.x * 64;
-    T acc[4][4] = {};
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        // A tile 64 x 16: thread loads 4 entries; B tile 16 x 64: 4 entries
+    const int row0 = blockIdx.y * 32, col0 = blockIdx.x * 64;
+    float acc[2][4] = {};
+    float pa[2], pb[4];
+    auto fetch = [&](int k0) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int e = threadIdx.x + 256 * q;
-            const int ar = e >> 4, ak = e & 15;                   // A: row ar (0..63), k ak (0..15): consecutive threads walk k
-            sa[ak][ar] = (row0 + ar < M && k0 + ak < K) ? A[(size_t)(row0 + ar) * lda + k0 + ak] : T(0);
-            const int bk = e >> 6, bc = e & 63;                   // B: k bk (0..15), col bc (0..63): consecutive threads walk the columns
-            sb[bk][bc] = (k0 + bk < K && col0 + bc < N) ? B[(size_t)(k0 + bk) * ldb + col0 + bc] : T(0);
-        }
+        for (int q = 0; q < 2; ++q) { const int e = threadIdx.x + 256 * q, ar = e >> 4, ak = e & 15; pa[q] = (row0 + ar < M && k0 + ak < K) ? A[(size_t)(row0 + ar) * lda + k0 + ak] : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = threadIdx.x + 256 * q, bk = e >> 6, bc = e & 63; pb[q] = (k0 + bk < K && col0 + bc < N) ? B[(size_t)(k0 + bk) * ldb + col0 + bc] : 0.f; }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < K; k0 += 16) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { const int e = threadIdx.x + 256 * q; sa[e & 15][e >> 4] = pa[q]; }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const int e = threadIdx.x + 256 * q; sb[e >> 6][e & 63] = pb[q]; }
         __syncthreads();
+        if (k0 + 16 < K) fetch(k0 + 16);
 #pragma unroll
         for (int k = 0; k < 16; ++k) {
-            T a[4], b[4];
+            const float a0 = sa[k][ty * 2], a1 = sa[k][ty * 2 + 1];
+            float b[4];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) { a[u] = sa[k][ty * 4 + u]; b[u] = sb[k][tx * 4 + u]; }
+            for (int v = 0; v < 4; ++v) b[v] = sb[k][tx * 4 + v];
 #pragma unroll
-            for (int u = 0; u < 4; ++u)
-#pragma unroll
-                for (int v = 0; v < 4; ++v) acc[u][v] += a[u] * b[v];
+            for (int v = 0; v < 4; ++v) { acc[0][v] += a0 * b[v]; acc[1][v] += a1 * b[v]; }
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int u = 0; u < 4; ++u)
+    for (int u = 0; u < 2; ++u)
 #pragma unroll
         for (int v = 0; v < 4; ++v) {
-            const int r = row0 + ty * 4 + u, c = col0 + tx * 4 + v;
+            const int r = row0 + ty * 2 + u, c = col0 + tx * 4 + v;
             if (r < M && c < N) C[(size_t)r * ldc + c] = acc[u][v];
         }
 }
 
-// the run-time copies: Etf = f32(E^T) [nd x n3], Gf = f32(G) [n3 x nd]
-template <typename T>
-__global__ __launch_bounds__(kBlock) void k_tail_pack(int n3, int nd, const T* __restrict__ E, const T* __restrict__ G, float* __restrict__ Etf, float* __restrict__ Gf) {
+// the run-time copy of E^T: Etf [nd x n3] = E^T
+__global__ __launch_bounds__(kBlock) void k_transpose_f32(int n3, int nd, const float* __restrict__ E, float* __restrict__ Etf) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= n3 * nd) return;
     const int i = t / nd, m = t % nd;
-    Gf[t] = (float)G[t];
-    Etf[(size_t)m * n3 + i] = (float)E[t];
+    Etf[(size_t)m * n3 + i] = E[t];
 }
 
 // z = B r for a dense f32 matrix with LONG rows (n_cols in the thousands): one workgroup per row, every load of a thread issued
@@ -771,7 +774,7 @@ __global__ __launch_bounds__(kBlock) void k_rowdot_wg(int n_rows, int n_cols, co
     const int done = st->done;
     const int row = blockIdx.x;
     const float* b = Bf + (size_t)row * n_cols;
-    constexpr int U = 4;
+    constexpr int U = 12;                                    // 3 072 columns per trip: a level of <= 1 024 block rows is ONE trip
     T acc = 0;
     float b0 = (int)threadIdx.x < n_cols ? b[threadIdx.x] : 0.f;
     issue_before_exit(b0);
@@ -793,7 +796,7 @@ template <typename T, int PK>
 __global__ __launch_bounds__(kBlock) void k_tail_up(int n, const int* __restrict__ ptr, const int* __restrict__ col, const uint32_t* __restrict__ Apm, const HT<T>* __restrict__ Dinv,
                                                     const T* __restrict__ omega_ptr, const T* __restrict__ z1, int nd, const float* __restrict__ Gf, const T* __restrict__ t,
                                                     T* __restrict__ z, const CgState<T>* __restrict__ st) {
-    __shared__ T red[kWavesPerBlock];
+    __shared__ T red6[kWavesPerBlock * 6];
     const int done = st->done;
     const int i = blockIdx.x;
     int p0 = ptr[i];
@@ -814,15 +817,20 @@ __global__ __launch_bounds__(kBlock) void k_tail_up(int n, const int* __restrict
         const T v0 = v[0], v1 = v[1], v2 = v[2];
         s0 += b[0] * v0 + b[1] * v1 + b[2] * v2; s1 += b[3] * v0 + b[4] * v1 + b[5] * v2; s2 += b[6] * v0 + b[7] * v1 + b[8] * v2;
     }
-    s0 = block_sum<T>(s0, red); s1 = block_sum<T>(s1, red); s2 = block_sum<T>(s2, red);
-    d0 = block_sum<T>(d0, red); d1 = block_sum<T>(d1, red); d2 = block_sum<T>(d2, red);
+    // six sums, ONE barrier: per-wave shuffles, then thread 0 adds the four waves' partials
+    s0 = wave_sum<T>(s0); s1 = wave_sum<T>(s1); s2 = wave_sum<T>(s2); d0 = wave_sum<T>(d0); d1 = wave_sum<T>(d1); d2 = wave_sum<T>(d2);
+    if ((threadIdx.x & 63) == 0) { T* q = red6 + (threadIdx.x >> 6) * 6; q[0] = s0; q[1] = s1; q[2] = s2; q[3] = d0; q[4] = d1; q[5] = d2; }
+    __syncthreads();
     if (threadIdx.x == 0) {
+        T v[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { v[k] = red6[k]; for (int wv = 1; wv < kWavesPerBlock; ++wv) v[k] += red6[wv * 6 + k]; }
         const T w = *omega_ptr;
         const HT<T>* d = Dinv + (size_t)i * 9;
         const T* zi = z1 + (size_t)i * 3;
-        z[(size_t)i * 3] = T(2) * zi[0] - w * (T(d[0]) * s0 + T(d[1]) * s1 + T(d[2]) * s2) + d0;
-        z[(size_t)i * 3 + 1] = T(2) * zi[1] - w * (T(d[3]) * s0 + T(d[4]) * s1 + T(d[5]) * s2) + d1;
-        z[(size_t)i * 3 + 2] = T(2) * zi[2] - w * (T(d[6]) * s0 + T(d[7]) * s1 + T(d[8]) * s2) + d2;
+        z[(size_t)i * 3] = T(2) * zi[0] - w * (T(d[0]) * v[0] + T(d[1]) * v[1] + T(d[2]) * v[2]) + v[3];
+        z[(size_t)i * 3 + 1] = T(2) * zi[1] - w * (T(d[3]) * v[0] + T(d[4]) * v[1] + T(d[5]) * v[2]) + v[4];
+        z[(size_t)i * 3 + 2] = T(2) * zi[2] - w * (T(d[6]) * v[0] + T(d[7]) * v[1] + T(d[8]) * v[2]) + v[5];
     }
 }
 

@@ -662,6 +662,26 @@ template <typename T> struct Engine : IEngine {
         if (h_rho) (void)hipHostFree(h_rho);
         HIP_OK(hipHostMalloc((void**)&h_rho, sizeof(T) * 16 * 2 * kRhoBlocks));
         lin_count = 0; hier_age = -1;
+        {   // S is symmetric: k_schur_blocks sums the blocks on and above the diagonal, the others are mirrored (half of the set-up's most
+            // expensive gather: 137 us per hierarchy build at 100k poses)
+            DevLevel<T>& L0 = lv[0];
+            int *nup = nullptr, *uoff = nullptr, *flag = nullptr;
+            n_upper0 = -1;
+            if (int rc = dalloc(&nup, (size_t)L0.n)) return rc;
+            if (int rc = dalloc(&uoff, (size_t)L0.n + 1)) return rc;
+            if (int rc = dalloc(&flag, 4)) return rc;
+            if (int rc = dalloc(&mirror0, (size_t)L0.nnzA)) return rc;
+            if (int rc = dalloc(&upper0, (size_t)L0.nnzA)) return rc;
+            if (int rc = fill_zero(flag, 4 * sizeof(int))) return rc;
+            hipLaunchKernelGGL(k_count_upper, dim3((L0.n + 255) / 256), dim3(256), 0, cs(), L0.n, (const int*)L0.A_ptr, (const int*)L0.A_col, nup);
+            hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), L0.n, (const int*)nup, uoff);
+            hipLaunchKernelGGL(k_sym_mirror, dim3((L0.n + 255) / 256), dim3(256), 0, cs(), L0.n, (const int*)L0.A_ptr, (const int*)L0.A_col, (const int*)uoff, mirror0, upper0, flag);
+            int h2[2] = {0, 0};
+            HIP_OK(hipMemcpyAsync(&h2[0], uoff + L0.n, sizeof(int), hipMemcpyDeviceToHost, cs()));
+            HIP_OK(hipMemcpyAsync(&h2[1], flag, sizeof(int), hipMemcpyDeviceToHost, cs()));
+            HIP_OK(hipStreamSynchronize(cs()));
+            if (!h2[1]) n_upper0 = h2[0];      // (a pattern that is not structurally symmetric — it always is — keeps every block summed)
+        }
         // the bottom of the cycle as one dense operator (tsgo_amg_kernels.h: k_bottom_*): the last explicit level when it is small enough
         // and runs V(1,1); and the level above it in factored form (k_tail_*) when that one is small too
         const size_t nl = lv.size();
@@ -671,7 +691,6 @@ template <typename T> struct Engine : IEngine {
             const size_t n3 = (size_t)lv.back().n * 3, nd = (size_t)nb_last * 3;
             if (int rc = dalloc(&bot_S, n3 * n3)) return rc;
             if (int rc = dalloc(&bot_B, n3 * n3)) return rc;
-            if (int rc = dalloc(&bot_Bs, n3 * n3)) return rc;
             if (int rc = dalloc(&bot_P, n3 * nd)) return rc;
             if (int rc = dalloc(&bot_E, n3 * nd)) return rc;
             if (int rc = dalloc(&bot_F, n3 * nd)) return rc;
@@ -679,17 +698,17 @@ template <typename T> struct Engine : IEngine {
         }
         if (tail2) {
             const size_t n3 = (size_t)lv[nl - 2].n * 3, nd = (size_t)lv.back().n * 3;
-            if (int rc = dalloc(&tail_E, n3 * nd)) return rc;
-            if (int rc = dalloc(&tail_G, n3 * nd)) return rc;
+            if (int rc = dalloc(&tail_Ef, n3 * nd)) return rc;
             if (int rc = dalloc(&tail_Etf, n3 * nd)) return rc;
             if (int rc = dalloc(&tail_Gf, n3 * nd)) return rc;
             if (int rc = dalloc(&tail_t, nd)) return rc;
         }
         return 0;
     }
+    int n_upper0 = -1; int *mirror0 = nullptr, *upper0 = nullptr;      // level 0: blocks on / above the diagonal, and the mirror of every block below it
     bool bottom_dense = false, tail2 = false;
-    T *bot_S = nullptr, *bot_B = nullptr, *bot_Bs = nullptr, *bot_P = nullptr, *bot_E = nullptr, *bot_F = nullptr; float* bot_Bf = nullptr;
-    T *tail_E = nullptr, *tail_G = nullptr, *tail_t = nullptr; float *tail_Etf = nullptr, *tail_Gf = nullptr;
+    T *bot_S = nullptr, *bot_B = nullptr, *bot_P = nullptr, *bot_E = nullptr, *bot_F = nullptr; float* bot_Bf = nullptr;
+    T* tail_t = nullptr; float *tail_Ef = nullptr, *tail_Etf = nullptr, *tail_Gf = nullptr;
     // B = W + S W + E C E^T of the last explicit level (after k_dense_inverse, and again whenever the level's damping changes), then
     // E = P - W (A P) and G = E B of the level above it
     int launch_bottom_setup() {
@@ -706,17 +725,17 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL((k_small_gemm<T, 0>), dim3(tiles(nd), tiles(n3)), dim3(256), 0, stream, n3, nd, n3, (const T*)bot_S, n3, (const T*)bot_P, nd, bot_E, nd);          // E = S P
             hipLaunchKernelGGL((k_small_gemm<T, 0>), dim3(tiles(nd), tiles(n3)), dim3(256), 0, stream, n3, nd, nd, (const T*)bot_E, nd, (const T*)inv_last, nd, bot_F, nd);      // F = E C
             hipLaunchKernelGGL((k_small_gemm<T, 1>), dim3(tiles(n3), tiles(n3)), dim3(256), 0, stream, n3, n3, nd, (const T*)bot_F, nd, (const T*)bot_E, nd, bot_B, n3);         // G = F E^T
-            hipLaunchKernelGGL((k_bottom_finish<T>), dim3(grid_for(n3 * n3)), dim3(kBlock), 0, stream, n3, (const T*)bot_S, (const H*)L.Dinv, om, (const T*)bot_B, bot_Bf, bot_Bs);
+            hipLaunchKernelGGL((k_bottom_finish<T>), dim3(grid_for(n3 * n3)), dim3(kBlock), 0, stream, n3, (const T*)bot_S, (const H*)L.Dinv, om, (const T*)bot_B, bot_Bf, (T*)nullptr);
         }
         if (tail2) {
             DevLevel<T>& L = lv[lv.size() - 2];
             const int n3 = L.n * 3, nd = lv.back().n * 3;
             const T* om = omega_dev + (lv.size() - 2);
-            HIP_OK(hipMemsetAsync(tail_E, 0, sizeof(T) * (size_t)n3 * nd, stream));
-            hipLaunchKernelGGL((k_scatter_blocks<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, (const int*)L.P_row, (const int*)L.P_col, (const H*)L.P, nd, tail_E);
-            hipLaunchKernelGGL((k_tail_E<T>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, (const int*)L.T_ptr, (const int*)L.T_col, (const H*)L.Tv, (const H*)L.Dinv, om, nd, tail_E);      // E = P - W (A P)
-            hipLaunchKernelGGL((k_gemm64<T>), dim3((nd + 63) / 64, (n3 + 63) / 64), dim3(256), 0, stream, n3, nd, nd, (const T*)tail_E, nd, (const T*)bot_Bs, nd, tail_G, nd);      // G = E B
-            hipLaunchKernelGGL((k_tail_pack<T>), dim3(grid_for(n3 * nd)), dim3(kBlock), 0, stream, n3, nd, (const T*)tail_E, (const T*)tail_G, tail_Etf, tail_Gf);
+            HIP_OK(hipMemsetAsync(tail_Ef, 0, sizeof(float) * (size_t)n3 * nd, stream));
+            hipLaunchKernelGGL((k_scatter_blocks<T>), dim3(grid_for(L.nnzP)), dim3(kBlock), 0, stream, L.nnzP, (const int*)L.P_row, (const int*)L.P_col, (const H*)L.P, nd, tail_Ef);
+            hipLaunchKernelGGL((k_tail_E<T>), dim3(grid_for(L.n, 64)), dim3(kBlock), 0, stream, L.n, (const int*)L.T_ptr, (const int*)L.T_col, (const H*)L.Tv, (const H*)L.Dinv, om, nd, tail_Ef);      // E = P - W (A P)
+            hipLaunchKernelGGL(k_gemm_f32, dim3((nd + 63) / 64, (n3 + 31) / 32), dim3(256), 0, stream, n3, nd, nd, (const float*)tail_Ef, nd, (const float*)bot_Bf, nd, tail_Gf, nd);      // G = E B
+            hipLaunchKernelGGL(k_transpose_f32, dim3(grid_for(n3 * nd)), dim3(kBlock), 0, stream, n3, nd, (const float*)tail_Ef, tail_Etf);
         }
         return 0;
     }
@@ -1111,9 +1130,11 @@ template <typename T> struct Engine : IEngine {
         // sharded: off-diagonal blocks are partial sums over this rank's landmarks and ODOM rows; the diagonal (from the
         // all-reduced linearisation partials, identical everywhere) is contributed by rank 0 alone; one all-reduce
         // makes level 0 whole and identical on every rank, everything below it is then computed redundantly
-        hipLaunchKernelGGL((k_schur_blocks<T>), dim3(grid_for(L0.nnzA)), dim3(kBlock), 0, stream, L0.nnzA, L0.A_row, L0.A_col, sc_ptr, sc_si, sc_sk,
+        const int n_sum = n_upper0 >= 0 ? n_upper0 : L0.nnzA;
+        hipLaunchKernelGGL((k_schur_blocks<T>), dim3(grid_for(n_sum)), dim3(kBlock), 0, stream, n_sum, L0.A_row, L0.A_col, sc_ptr, sc_si, sc_sk,
                            sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A, pr.rank == 0 ? 1 : 0,
-                           to.idx, oj() ? 1 : 0);
+                           to.idx, oj() ? 1 : 0, (const int*)(n_upper0 >= 0 ? upper0 : nullptr));
+        if (n_upper0 >= 0) hipLaunchKernelGGL((k_mirror_blocks<T>), dim3(grid_for(L0.nnzA, 9)), dim3(kBlock), 0, stream, L0.nnzA, (const int*)mirror0, L0.A);
         if (int rc = allreduce_h(L0.A, (size_t)L0.nnzA * 9)) return rc;
         if (explicit0) do { if (cy16) hipLaunchKernelGGL((k_to_planes<T, 1>), dim3(grid_for(L0.n, 8)), dim3(kBlock), 0, stream, L0.n, (const int*)L0.A_ptr, (const H*)L0.A, L0.Apm); else hipLaunchKernelGGL((k_to_planes<T, 0>), dim3(grid_for(L0.n, 8)), dim3(kBlock), 0, stream, L0.n, (const int*)L0.A_ptr, (const H*)L0.A, L0.Apm); } while (0);
         for (size_t l = 0; l < lv.size(); ++l) {

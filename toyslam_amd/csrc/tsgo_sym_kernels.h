@@ -184,6 +184,15 @@ __global__ __launch_bounds__(kSymWave) void k_sym_fill(int n, const int* __restr
     }
 }
 
+// blocks on or above the diagonal per row of a pattern with sorted rows (level 0 of the hierarchy: k_schur_blocks sums those only)
+__global__ __launch_bounds__(256) void k_count_upper(int n, const int* __restrict__ zptr, const int* __restrict__ zcol, int* __restrict__ nup) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    int u = 0;
+    for (int z = zptr[i]; z < zptr[i + 1]; ++z) u += zcol[z] >= i;
+    nup[i] = u;
+}
+
 // UPPER products: mirror[z] = the block (c, i) for a block z = (i, c) below the diagonal, -1 on or above it; upper[u] = the
 // blocks on or above the diagonal in block order (uoff = exclusive scan of n_upper)
 __global__ __launch_bounds__(256) void k_sym_mirror(int n, const int* __restrict__ zptr, const int* __restrict__ zcol, const int* __restrict__ uoff,

@@ -42,8 +42,8 @@ import numpy as np  # noqa: E402
 # torch is imported by the ranks only (run_rank): the launching parent of a multi-GPU run must not initialise the GPU
 
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-PMC_TRAFFIC = os.path.join("profiles", "r03_pmc_traffic.json")   # rocprofv3 --pmc digest of this same command (tools/pmc_traffic.py)
-ROCPROF_STATS = os.path.join("profiles", "r03_rocprofv3_kernel_stats.csv")   # rocprofv3 --kernel-trace --stats of this same command
+PMC_TRAFFIC = os.path.join("profiles", "r04_pmc_traffic.json")   # rocprofv3 --pmc digest of this same command (tools/pmc_traffic.py)
+ROCPROF_STATS = os.path.join("profiles", "r04_rocprofv3_kernel_stats.csv")   # rocprofv3 --kernel-trace --stats of this same command
 KERNELS = {0: "k_schur_lm", 1: "k_schur_pose", 2: "k_cg_update", 3: "k_lin_lm", 4: "k_lin_pose"}
 
 

@@ -286,7 +286,7 @@ def test_eight_shards_of_config_3_all_reduce_buffers_of_equal_length():
 
 
 def test_eight_shards_of_config_5_agree_on_the_pose_table_shape():
-    """The same shape rule at 1 M poses / 9.1 M edges (BASELINE config 5): first, a middle and the last of eight ranks."""
+    """The same shape rule at 1 M poses / 10.1 M edges (BASELINE config 5): first, a middle and the last of eight ranks."""
     g = synth.make_config("c5_1m")
     infos = [probe(g, r, 8) for r in (0, 3, 7)]
     assert len({(i.lanes_per_pose, i.lanes_per_lm, i.n_pose) for i in infos}) == 1

@@ -7,7 +7,7 @@
 # 2. rocprofv3 --pmc passes (tools/pmc_traffic.py: FETCH_SIZE, WRITE_SIZE apart)  -> <out>/<tag>_pmc_digest.txt, _pmc_traffic.json
 # 3. the bench line itself, AFTER 1-2 were copied to where bench.py reads them    -> <out>/final_bench.json
 # 4. tools/check_roofline.py: every fraction recomputed from the CSV              -> <out>/check_roofline.txt
-# For c3_100k the CSV / JSON go to profiles/r03_rocprofv3_kernel_stats.csv / r03_pmc_traffic.json (what bench.py reads); other
+# For c3_100k the CSV / JSON go to profiles/r04_rocprofv3_kernel_stats.csv / r04_pmc_traffic.json (what bench.py reads); other
 # workloads keep theirs under <out>/ (copy them to profiles/ by hand with the workload in the name).
 set -eo pipefail
 TAG=$1; W=${2:-c3_100k}; STEPS=${3:-20}; WARM=${4:-5}
@@ -22,8 +22,8 @@ cp "$STATS" "$OUT/kernel_stats.csv"
 echo "stats: $STATS"
 python3 "$ROOT/tools/pmc_traffic.py" "$OUT" "$TAG" $W > "$OUT/pmc_stdout.txt" 2>&1
 if [ "$W" = c3_100k ]; then
-  cp "$OUT/kernel_stats.csv" "$ROOT/profiles/r03_rocprofv3_kernel_stats.csv"
-  cp "$OUT/${TAG}_pmc_traffic.json" "$ROOT/profiles/r03_pmc_traffic.json"
+  cp "$OUT/kernel_stats.csv" "$ROOT/profiles/r04_rocprofv3_kernel_stats.csv"
+  cp "$OUT/${TAG}_pmc_traffic.json" "$ROOT/profiles/r04_pmc_traffic.json"
 fi
 cd "$ROOT"
 python3 bench.py --steps $STEPS --warmup $WARM --workload $W > "$OUT/final_bench.json" 2> "$OUT/bench.err"

@@ -6,7 +6,7 @@
 #   usage: tools/sanitize_host.sh [log file]
 set -euo pipefail
 cd "$(dirname "$0")/.."
-out=${1:-profiles/r03_sanitizers_host.log}
+out=${1:-profiles/r04_sanitizers_host.log}
 so=/tmp/libtsgo_host_asan.so
 src="host/problem.cpp host/amg.cpp host/codec.cpp host/synth.cpp host/host_api.cpp host/errors.cpp"
 (cd toyslam_amd/csrc && g++ -O1 -g -std=c++17 -fPIC -Wall -pthread -fsanitize=address,undefined -fno-sanitize-recover=undefined -fno-omit-frame-pointer -shared -o $so $src)

@@ -58,10 +58,11 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
                                                          const uint32_t* __restrict__ oslot, Table<T> tb, const T* __restrict__ od_dyn,
                                                          size_t od_slots, const T* __restrict__ lmrec, const T* __restrict__ ps,
                                                          const T* __restrict__ part, HT<T>* __restrict__ A, int diag_on,
-                                                         const uint32_t* __restrict__ od_idx, int odom_analytic, const int* __restrict__ which) {
+                                                         const uint32_t* __restrict__ od_idx, int odom_analytic, const int* __restrict__ which,
+                                                         const int* __restrict__ lower_of) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= nnz) return;
-    const int b = which ? which[t] : t;      // which: the blocks on or above the diagonal (S is symmetric: the others are mirrored, k_mirror_blocks)
+    const int b = which ? which[t] : t;      // which: the blocks on or above the diagonal; S is symmetric: each also writes its mirror (lower_of)
     const int i = blk_row[b], k = blk_col[b];
     HT<T>* o = A + (size_t)b * 9;
     if (i == k) {
@@ -109,6 +110,16 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
     }
 #pragma unroll
     for (int m = 0; m < 9; ++m) o[m] = -acc[m] + d[m];
+    if (lower_of) {
+        const int lo = lower_of[b];
+        if (lo >= 0) {
+            HT<T>* q = A + (size_t)lo * 9;
+#pragma unroll
+            for (int x = 0; x < 3; ++x)
+#pragma unroll
+                for (int y = 0; y < 3; ++y) q[3 * x + y] = o[3 * y + x];
+        }
+    }
 }
 
 template <typename T>

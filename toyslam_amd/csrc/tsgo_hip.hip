@@ -676,6 +676,9 @@ template <typename T> struct Engine : IEngine {
             hipLaunchKernelGGL(k_count_upper, dim3((L0.n + 255) / 256), dim3(256), 0, cs(), L0.n, (const int*)L0.A_ptr, (const int*)L0.A_col, nup);
             hipLaunchKernelGGL(k_sym_scan, dim3(1), dim3(1024), 0, cs(), L0.n, (const int*)nup, uoff);
             hipLaunchKernelGGL(k_sym_mirror, dim3((L0.n + 255) / 256), dim3(256), 0, cs(), L0.n, (const int*)L0.A_ptr, (const int*)L0.A_col, (const int*)uoff, mirror0, upper0, flag);
+            if (int rc = dalloc(&lower0, (size_t)L0.nnzA)) return rc;
+            HIP_OK(hipMemsetAsync(lower0, 0xff, sizeof(int) * (size_t)L0.nnzA, cs()));
+            hipLaunchKernelGGL(k_invert_mirror, dim3((L0.nnzA + 255) / 256), dim3(256), 0, cs(), L0.nnzA, (const int*)mirror0, lower0);
             int h2[2] = {0, 0};
             HIP_OK(hipMemcpyAsync(&h2[0], uoff + L0.n, sizeof(int), hipMemcpyDeviceToHost, cs()));
             HIP_OK(hipMemcpyAsync(&h2[1], flag, sizeof(int), hipMemcpyDeviceToHost, cs()));
@@ -705,7 +708,7 @@ template <typename T> struct Engine : IEngine {
         }
         return 0;
     }
-    int n_upper0 = -1; int *mirror0 = nullptr, *upper0 = nullptr;      // level 0: blocks on / above the diagonal, and the mirror of every block below it
+    int n_upper0 = -1; int *mirror0 = nullptr, *upper0 = nullptr, *lower0 = nullptr;      // level 0: blocks on / above the diagonal, and the mirror of every block below it
     bool bottom_dense = false, tail2 = false;
     T *bot_S = nullptr, *bot_B = nullptr, *bot_P = nullptr, *bot_E = nullptr, *bot_F = nullptr; float* bot_Bf = nullptr;
     T* tail_t = nullptr; float *tail_Ef = nullptr, *tail_Etf = nullptr, *tail_Gf = nullptr;
@@ -1133,8 +1136,7 @@ template <typename T> struct Engine : IEngine {
         const int n_sum = n_upper0 >= 0 ? n_upper0 : L0.nnzA;
         hipLaunchKernelGGL((k_schur_blocks<T>), dim3(grid_for(n_sum)), dim3(kBlock), 0, stream, n_sum, L0.A_row, L0.A_col, sc_ptr, sc_si, sc_sk,
                            sc_optr, sc_os, tp, (const T*)to.dyn, to.slots, (const T*)lmrec, (const T*)ps, (const T*)part, L0.A, pr.rank == 0 ? 1 : 0,
-                           to.idx, oj() ? 1 : 0, (const int*)(n_upper0 >= 0 ? upper0 : nullptr));
-        if (n_upper0 >= 0) hipLaunchKernelGGL((k_mirror_blocks<T>), dim3(grid_for(L0.nnzA, 9)), dim3(kBlock), 0, stream, L0.nnzA, (const int*)mirror0, L0.A);
+                           to.idx, oj() ? 1 : 0, (const int*)(n_upper0 >= 0 ? upper0 : nullptr), (const int*)(n_upper0 >= 0 ? lower0 : nullptr));
         if (int rc = allreduce_h(L0.A, (size_t)L0.nnzA * 9)) return rc;
         if (explicit0) do { if (cy16) hipLaunchKernelGGL((k_to_planes<T, 1>), dim3(grid_for(L0.n, 8)), dim3(kBlock), 0, stream, L0.n, (const int*)L0.A_ptr, (const H*)L0.A, L0.Apm); else hipLaunchKernelGGL((k_to_planes<T, 0>), dim3(grid_for(L0.n, 8)), dim3(kBlock), 0, stream, L0.n, (const int*)L0.A_ptr, (const H*)L0.A, L0.Apm); } while (0);
         for (size_t l = 0; l < lv.size(); ++l) {

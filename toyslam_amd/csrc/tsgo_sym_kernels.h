@@ -193,6 +193,14 @@ __global__ __launch_bounds__(256) void k_count_upper(int n, const int* __restric
     nup[i] = u;
 }
 
+// lower_of[u] = the block below the diagonal whose mirror u is (-1: a diagonal block), from mirror[] of k_sym_mirror
+__global__ __launch_bounds__(256) void k_invert_mirror(int nnz, const int* __restrict__ mirror, int* __restrict__ lower_of) {
+    const int z = blockIdx.x * 256 + threadIdx.x;
+    if (z >= nnz) return;
+    const int m = mirror[z];
+    if (m >= 0) lower_of[m] = z;
+}
+
 // UPPER products: mirror[z] = the block (c, i) for a block z = (i, c) below the diagonal, -1 on or above it; upper[u] = the
 // blocks on or above the diagonal in block order (uoff = exclusive scan of n_upper)
 __global__ __launch_bounds__(256) void k_sym_mirror(int n, const int* __restrict__ zptr, const int* __restrict__ zcol, const int* __restrict__ uoff,

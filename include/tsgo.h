@@ -26,8 +26,13 @@ extern "C" {
  * vertex/VertexType.h:3-7 (Se2 = 0, Point2 = 1), edge/EdgeType.h:3-7 (Se2 = 0 "ODOM", Se2Point2 = 1
  * "LM"), python twin python/optimizer/opt_graph.py:7-18.
  *   v_pos  : 3 doubles per vertex: (x, y, theta) for Se2, (x, y, 0) for Point2
+ *   e_type : 0 ODOM, 1 LM — the two the reference's wire format carries — and 2 = VIRTUAL LANDMARK MEASUREMENT, behind this ABI only
+ *            (README.md:53 "Further development: ... Virtual Meas."; the reference keeps a sketch commented out,
+ *            python/optimizer/edges2d.py:83-121): two Se2 vertices that observed the same physical point, no landmark vertex;
+ *            residual e = T1 p1 - T2 p2 (2), Jacobians [I | dR1/dth p1] and -[I | dR2/dth p2], 2 x 2 diagonal information
  *   e_meas : 9 doubles per edge: ODOM = the 3x3 measurement row-major (EdgeSe2.h); LM = (range,
- *            bearing, 0...) (EdgeSe2Point2d.h:34-35)
+ *            bearing, 0...) (EdgeSe2Point2d.h:34-35); virtual landmark = (range1, bearing1, range2, bearing2, 0...): the point
+ *            as seen from id1 and from id2
  *   e_inf  : 3 doubles per edge: the diagonal of the information matrix (the wire format carries
  *            nothing else, DeserializeGraph.h:123-147); LM uses the first two
  *   fixed  : vertex ids given to FixVertex; a repeated id adds the gauge term once per occurrence

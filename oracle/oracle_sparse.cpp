@@ -35,7 +35,7 @@ extern "C" int oracle_get_odom_jacobian(void);      // oracle_dense.cpp: 0 = the
 
 namespace {
 
-using tsgo::kNoEdge; using tsgo::kWave; using tsgo::kDirBit;
+using tsgo::kNoEdge; using tsgo::kWave; using tsgo::kDirBit; using tsgo::kVlmBit; using tsgo::kPoseMask;
 typedef void (*allreduce_fn)(double* buf, int64_t n, void* ctx);
 
 struct Twin {
@@ -52,6 +52,7 @@ struct Twin {
     std::vector<double> gscratch;
     bool use_amg = false;
     bool analytic = false;                          // analytic ODOM Jacobians (extension; tsgo_math.h: odom_blocks)
+    bool general = false;                           // eight planes per pose-pose slot: analytic ODOM Jacobians or virtual landmark measurements in the graph
     double lambda = 0; bool zero_fixed = false;     // the Python optimizer's rules (graph_optimizer.py:42,150), as Engine::launch_lin; 0 / false: cpu eigen
     double step = tsgo::kStepScale;
     int n_lin = 0;
@@ -75,7 +76,8 @@ struct Twin {
         }
         analytic = oracle_get_odom_jacobian() != 0;
         pr.odom_analytic = analytic;
-        pa.assign(4 * pr.by_pose.slots(), 0); la.assign(4 * pr.by_lm.slots(), 0); oa.assign((analytic ? 6 : 3) * pr.odom.slots(), 0);
+        general = analytic || pr.has_vlm;      // pose-pose slots in general form (tsgo_math.h), as Engine::oj()
+        pa.assign(4 * pr.by_pose.slots(), 0); la.assign(4 * pr.by_lm.slots(), 0); oa.assign((general ? (int)tsgo::PP_PLANES : 3) * pr.odom.slots(), 0);
         dlinv.assign((size_t)L * 3, 0); u.assign((size_t)L * 2, 0); t.assign((size_t)L * 2, 0);
         part.assign((size_t)P * 18 + 1, 0);
         dp.assign((size_t)P * 6, 0); minv.assign((size_t)P * 6, 0);
@@ -136,10 +138,11 @@ struct Twin {
                 for (int m = 0; m < 9; ++m) o[m] = -acc[m];
                 for (int q = amg.schur.od_ptr[b]; q < amg.schur.od_ptr[b + 1]; ++q) {
                     const size_t e = amg.schur.od_slot[q];
-                    if (analytic) {
-                        const double k00 = oa[e], k01 = oa[SO + e], k11 = oa[2 * SO + e], g0 = oa[3 * SO + e], g1 = oa[4 * SO + e], w = oa[5 * SO + e];
-                        o[0] -= k00; o[1] -= k01; o[3] -= k01; o[4] -= k11; o[8] -= w;
-                        if (pr.odom.idx[e] & kDirBit) { o[2] += g0; o[5] += g1; } else { o[6] += g0; o[7] += g1; }
+                    if (general) {      // the slot's own row block [[-K, c], [r^T, -kappa]] (tsgo_math.h; k_schur_blocks)
+                        double h[tsgo::PP_PLANES];
+                        for (int m = 0; m < tsgo::PP_PLANES; ++m) h[m] = oa[(size_t)m * SO + e];
+                        o[0] -= h[tsgo::PP_K00]; o[1] -= h[tsgo::PP_K01]; o[3] -= h[tsgo::PP_K01]; o[4] -= h[tsgo::PP_K11];
+                        o[2] += h[tsgo::PP_C0]; o[5] += h[tsgo::PP_C1]; o[6] += h[tsgo::PP_R0]; o[7] += h[tsgo::PP_R1]; o[8] -= h[tsgo::PP_KAPPA];
                     } else { o[0] -= oa[e]; o[4] -= oa[SO + e]; o[8] -= oa[2 * SO + e]; }
                 }
             }
@@ -263,22 +266,34 @@ struct Twin {
             o18[15] = -(c * wu0 - sn * wu1); o18[16] = -(sn * wu0 + c * wu1); o18[17] = wut;
             // ODOM rows (both directions are listed; chi^2 counted at id1 only)
             for_slots(od, i, [&](size_t k) {
-                const uint32_t raw = od.idx[k]; const bool second = raw & kDirBit; const uint32_t j = raw & ~kDirBit;
+                const uint32_t raw = od.idx[k]; const bool second = raw & kDirBit; const uint32_t j = raw & kPoseMask;
                 const double* me = &ps[4 * (size_t)i]; const double* ot = &ps[4 * (size_t)j];
                 const double* a = second ? ot : me; const double* b = second ? me : ot;
                 double mi[6], w[3];
                 for (int m = 0; m < 6; ++m) mi[m] = od.plane(tsgo::OD_MI0 + m)[k];
                 for (int m = 0; m < 3; ++m) w[m] = od.plane(tsgo::OD_W0 + m)[k];
+                if (raw & kVlmBit) {      // virtual landmark measurement (as k_lin_pose<.., 1>): mi = (pox, poy, pnx, pny), w = (w0, w1)
+                    const auto v = tsgo::vlm_linearize<double>(me[0], me[1], me[2], me[3], ot[0], ot[1], ot[2], ot[3], mi[0], mi[1], mi[2], mi[3], w[0], w[1]);
+                    double h[tsgo::PP_PLANES]; tsgo::vlm_slot<double>(v, h);
+                    for (int m = 0; m < tsgo::PP_PLANES; ++m) oa[(size_t)m * SO + k] = h[m];
+                    o18[0] += v.om0; o18[3] += v.om1; o18[2] += v.om0 * v.u0; o18[4] += v.om1 * v.u1; o18[5] += v.om0 * v.u0 * v.u0 + v.om1 * v.u1 * v.u1;
+                    o18[6] -= v.om0 * v.d0; o18[7] -= v.om1 * v.d1; o18[8] -= v.om0 * v.u0 * v.d0 + v.om1 * v.u1 * v.d1;
+                    if (!second) chi += v.rho;
+                    return;
+                }
                 auto o = tsgo::odom_linearize<double>(a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], mi, w);
                 if (analytic) {                                              // tsgo_math.h: odom_blocks (as k_lin_pose<.., OJ = 1>)
                     const auto ob = tsgo::odom_blocks<double>(o, a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3], mi);
-                    const double six[6] = {ob.k00, ob.k01, ob.k11, ob.g0, ob.g1, ob.w};
-                    for (int m = 0; m < 6; ++m) oa[m * SO + k] = six[m];
+                    double h[tsgo::PP_PLANES] = {ob.k00, ob.k01, ob.k11, second ? ob.g0 : 0.0, second ? ob.g1 : 0.0, second ? 0.0 : ob.g0, second ? 0.0 : ob.g1, ob.w};
+                    for (int m = 0; m < tsgo::PP_PLANES; ++m) oa[(size_t)m * SO + k] = h[m];
                     o18[0] += ob.k00; o18[1] += ob.k01; o18[3] += ob.k11;
                     if (!second) { o18[2] -= ob.g0; o18[4] -= ob.g1; o18[5] += ob.s + ob.w; o18[6] += ob.h0; o18[7] += ob.h1; o18[8] += ob.kt - ob.ht; }
                     else { o18[5] += ob.w; o18[6] -= ob.h0; o18[7] -= ob.h1; o18[8] -= ob.kt; }
                 } else {
-                    for (int m = 0; m < 3; ++m) oa[m * SO + k] = o.a[m];
+                    if (general) {
+                        const double h[tsgo::PP_PLANES] = {o.a[0], 0.0, o.a[1], 0.0, 0.0, 0.0, 0.0, o.a[2]};
+                        for (int m = 0; m < tsgo::PP_PLANES; ++m) oa[(size_t)m * SO + k] = h[m];
+                    } else for (int m = 0; m < 3; ++m) oa[m * SO + k] = o.a[m];
                     o18[0] += o.a[0]; o18[3] += o.a[1]; o18[5] += o.a[2];
                     const double sg = second ? -1.0 : 1.0;                       // b1 += W e, b2 -= W e
                     for (int m = 0; m < 3; ++m) o18[6 + m] += sg * o.a[m] * o.e[m];
@@ -354,12 +369,12 @@ struct Twin {
                 double d0, d1, d2; tsgo::sym3_mul(&dp[6 * (size_t)i], v0, v1, v2, d0, d1, d2);
                 o0 += d0; o1 += d1; o2 += d2;
                 for_slots(od, i, [&](size_t k) {
-                    const uint32_t j = od.idx[k] & ~kDirBit;
+                    const uint32_t j = od.idx[k] & kPoseMask;
                     const double* vj = &v[3 * (size_t)j];
-                    if (analytic) {
-                        const double k00 = oa[k], k01 = oa[SO + k], k11 = oa[2 * SO + k], g0 = oa[3 * SO + k], g1 = oa[4 * SO + k], w = oa[5 * SO + k];
-                        o0 -= k00 * vj[0] + k01 * vj[1]; o1 -= k01 * vj[0] + k11 * vj[1]; o2 -= w * vj[2];
-                        if (od.idx[k] & kDirBit) { o0 += g0 * vj[2]; o1 += g1 * vj[2]; } else o2 += g0 * vj[0] + g1 * vj[1];
+                    if (general) {
+                        double h[tsgo::PP_PLANES];
+                        for (int m = 0; m < tsgo::PP_PLANES; ++m) h[m] = oa[(size_t)m * SO + k];
+                        tsgo::pair_apply<double>(h, vj[0], vj[1], vj[2], o0, o1, o2);
                     } else { o0 -= oa[k] * vj[0]; o1 -= oa[SO + k] * vj[1]; o2 -= oa[2 * SO + k] * vj[2]; }
                 });
             }

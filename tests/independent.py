@@ -35,8 +35,13 @@ class Linearisation:
         A3[lm] = 0; B3[lm] = 0
         A3[lm, :2, :] = A[lm, :6].reshape(-1, 2, 3)
         B3[lm, :2, :2] = B[lm, :4].reshape(-1, 2, 2)
-        w = g.e_inf.copy(); w[lm, 2] = 0
-        e = e.copy(); e[lm, 2] = 0
+        vl = g.e_type == 2                                              # virtual landmark measurement: 2 x 3 and 2 x 3 (oracle_dense.cpp: vlm_edge)
+        A3[vl] = 0; B3[vl] = 0
+        A3[vl, :2, :] = A[vl, :6].reshape(-1, 2, 3)
+        B3[vl, :2, :] = B[vl, :6].reshape(-1, 2, 3)
+        two = lm | vl
+        w = g.e_inf.copy(); w[two, 2] = 0
+        e = e.copy(); e[two, 2] = 0
         chi = (w * e * e).sum(axis=1)                                   # e^T Omega e  (:91)
         tail = chi > HUBER_DELTA ** 2                                   # robustify (:36-46)
         sq = np.sqrt(np.where(tail, chi, 1.0))

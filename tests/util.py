@@ -71,3 +71,35 @@ def first_poses(g, n_poses):
     keep_e = np.isin(g.e_ids[:, 0], kept_ids) & np.isin(g.e_ids[:, 1], kept_ids)
     return GraphArrays(g.v_id[keep_v], g.v_type[keep_v], g.v_pos[keep_v], g.e_type[keep_e], g.e_ids[keep_e], g.e_meas[keep_e], g.e_inf[keep_e],
                        g.fixed[np.isin(g.fixed, kept_ids)])
+
+
+def with_virtual_landmarks(g, fraction=0.3, seed=0, keep_lm=True):
+    """A copy of `g` in which, for a `fraction` of the landmarks seen from at least two poses, one pair of its LM observations
+    (pose a, pose b) becomes ONE virtual landmark measurement (edge type 2, include/tsgo.h) between a and b:
+    meas = (range_a, bearing_a, range_b, bearing_b), information = the first observation's.  keep_lm = False also drops the two
+    LM edges it was made from (a landmark may then be left without edges: allowed)."""
+    import numpy as np
+    from toyslam_amd.graph import GraphArrays
+    rng = np.random.default_rng(seed)
+    by_lm = {}
+    for k in np.where(g.e_type == 1)[0]:
+        by_lm.setdefault(int(g.e_ids[k, 1]), []).append(int(k))
+    e_type, e_ids, e_meas, e_inf = [g.e_type], [g.e_ids], [g.e_meas], [g.e_inf]
+    drop = np.zeros(len(g.e_type), bool)
+    nt, ni, nm, nf = [], [], [], []
+    for lm, ks in by_lm.items():
+        if len(ks) < 2 or rng.random() > fraction:
+            continue
+        a, b = rng.choice(ks, size=2, replace=False)
+        if g.e_ids[a, 0] == g.e_ids[b, 0]:
+            continue
+        m = np.zeros(9); m[0:2] = g.e_meas[a, 0:2]; m[2:4] = g.e_meas[b, 0:2]
+        nt.append(2); ni.append([g.e_ids[a, 0], g.e_ids[b, 0]]); nm.append(m); nf.append([g.e_inf[a, 0], g.e_inf[a, 1], 0.0])
+        if not keep_lm:
+            drop[a] = drop[b] = True
+    if not nt:
+        return g.copy()
+    keep = ~drop
+    return GraphArrays(g.v_id, g.v_type, g.v_pos,
+                       np.concatenate([g.e_type[keep], np.array(nt, np.uint32)]), np.concatenate([g.e_ids[keep], np.array(ni, np.uint32)]),
+                       np.concatenate([g.e_meas[keep], np.array(nm)]), np.concatenate([g.e_inf[keep], np.array(nf)]), g.fixed)

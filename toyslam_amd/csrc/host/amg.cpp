@@ -397,8 +397,8 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
         for (int i = 0; i < P; ++i)
             for_slots(pr.odom, i, [&](size_t k) {
                 const uint32_t raw = pr.odom.idx[k];
-                if (raw & kDirBit) return;                    // this row is id2
-                const int j = (int)(raw & ~kDirBit);
+                if (raw & (kDirBit | kVlmBit)) return;        // this row is id2 / not an odometry edge (a virtual landmark measurement joins any two poses)
+                const int j = (int)(raw & kPoseMask);
                 if (j == i) return;
                 if (nout[i]++ == 0) { next[i] = j; ++indeg[j]; }
             });
@@ -447,7 +447,7 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
             for (int i = b; i < e; ++i) {
                 int n = 0, no = 0;
                 for_slots(pr.by_pose, i, [&](size_t) { ++n; });
-                for_slots(pr.odom, i, [&](size_t k) { if ((int)(pr.odom.idx[k] & ~kDirBit) != i) ++no; });
+                for_slots(pr.odom, i, [&](size_t k) { if ((int)(pr.odom.idx[k] & kPoseMask) != i) ++no; });
                 in.pp_ptr[i + 1] = n; in.od_ptr[i + 1] = no;
             }
         }, 4096);
@@ -458,7 +458,7 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
             for (int i = b; i < e; ++i) {
                 int at = in.pp_ptr[i], ao = in.od_ptr[i];
                 for_slots(pr.by_pose, i, [&](size_t k) { in.pp_lm[at] = (int)pr.by_pose.idx[k]; in.pp_slot[at] = (uint32_t)k; ++at; });
-                for_slots(pr.odom, i, [&](size_t k) { const int j = (int)(pr.odom.idx[k] & ~kDirBit); if (j != i) { in.od_col[ao] = j; in.od_slot[ao] = (uint32_t)k; ++ao; } });
+                for_slots(pr.odom, i, [&](size_t k) { const int j = (int)(pr.odom.idx[k] & kPoseMask); if (j != i) { in.od_col[ao] = j; in.od_slot[ao] = (uint32_t)k; ++ao; } });
             }
         }, 4096);
         in.obs_ptr = std::move(obs_ptr); in.obs_pose = std::move(obs_pose); in.obs_slot = std::move(obs_slot);
@@ -487,7 +487,7 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
                         if (obs_pose[q] != i) row.push_back({obs_pose[q], (uint32_t)k, obs_slot[q], 0});
                 });
                 for_slots(pr.odom, i, [&](size_t k) {
-                    const int j = (int)(pr.odom.idx[k] & ~kDirBit);
+                    const int j = (int)(pr.odom.idx[k] & kPoseMask);
                     if (j != i) row.push_back({j, (uint32_t)k, 0u, 1});
                 });
                 std::sort(row.begin(), row.end(), [](const Tup& p, const Tup& q) {
@@ -541,6 +541,7 @@ std::string build_amg(const Problem& pr, AmgSym& out, const AmgProgress* progres
     std::vector<char> rigid(P, 0);
     for (int i = 0; i < P; ++i) for_slots(pr.by_pose, i, [&](size_t) { rigid[i] = 1; });
     if (pr.odom_analytic) for (int i = 0; i < P; ++i) for_slots(pr.odom, i, [&](size_t) { rigid[i] = 1; });   // A = [[-M, q], ..]: q is the lever arm
+    if (pr.has_vlm) for (int i = 0; i < P; ++i) for_slots(pr.odom, i, [&](size_t k) { if (pr.odom.idx[k] & kVlmBit) rigid[i] = 1; });      // A = [I | dR/dth p]: a lever arm too
     L0.agg.resize(P);
     // aggregate size per level; research override: TSGO_AGG_LIST="8,4,4,8" (last entry repeats) or TSGO_AGG0 / TSGO_AGGC
     std::vector<int> agg_list;
@@ -617,7 +618,7 @@ std::string build_amg_sharded(const tsgo_graph& g, const Problem& local, AmgSym&
     BuildOptions bo; bo.lanes_per_pose = local.by_pose.G; bo.lanes_per_lm = local.by_lm.G;
     std::string err = build_problem(g, bo, full);
     if (!err.empty()) return err;
-    full.odom_analytic = local.odom_analytic;
+    full.odom_analytic = local.odom_analytic; full.has_vlm = local.has_vlm;
     if (full.P != local.P || full.pose_vertex != local.pose_vertex) return "shard and whole-graph pose numbering differ";
     AmgSym S;
     err = build_amg(full, S);

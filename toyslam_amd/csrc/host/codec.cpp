@@ -276,6 +276,11 @@ extern "C" int64_t tsgo_wire_encode_response(const tsgo_wire_graph* w, const dou
 
 extern "C" int64_t tsgo_wire_encode_request(const tsgo_graph* g, uint8_t* buf, size_t cap) {
     if (!g) return tsgo::set_error(-1, "tsgo_wire_encode_request: null argument");
+    for (int e = 0; e < g->n_edges; ++e)
+        if (g->e_type[e] > 1)
+            return tsgo::set_error(-2, "tsgo_wire_encode_request: edge " + std::to_string(e) + " has type " + std::to_string(g->e_type[e]) +
+                                           "; the wire format carries ODOM (0) and LM (1) edges only (remote/serialization/DeserializeGraph.h:93-95 throws on any other): "
+                                           "virtual landmark measurements exist behind the C ABI only");
     Writer o{buf, cap};
     o.u32(0);                                                           // graph_to_bytes.py:67 length prefix
     o.u32((uint32_t)g->n_vertices);                                     // :44

@@ -16,6 +16,12 @@
 
 namespace tsgo {
 
+void vlm_static(const double* meas, const double* inf, int side, double* out9) {
+    const double p1x = meas[0] * std::cos(meas[1]), p1y = meas[0] * std::sin(meas[1]), p2x = meas[2] * std::cos(meas[3]), p2y = meas[2] * std::sin(meas[3]);
+    out9[0] = side ? p2x : p1x; out9[1] = side ? p2y : p1y; out9[2] = side ? p1x : p2x; out9[3] = side ? p1y : p2y;
+    out9[4] = out9[5] = 0; out9[6] = inf[0]; out9[7] = inf[1]; out9[8] = 0;
+}
+
 bool invert3(const double* m, double* out) {
     double a[3][6];
     for (int i = 0; i < 3; ++i)
@@ -163,6 +169,10 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
             if (g.v_type[ev1[e]] != 0 || g.v_type[ev2[e]] != 1) return "LM edge " + std::to_string(e) + " must join an Se2 vertex to a Point2 vertex";
             ++deg_pose_lm[cls[ev1[e]]]; ++deg_lm[cls[ev2[e]]];
             ++pr.n_lm_edges_total;
+        } else if (t == 2) {      // virtual landmark measurement: a pose-pose edge in the ODOM table (tsgo_math.h: vlm_linearize)
+            if (g.v_type[ev1[e]] != 0 || g.v_type[ev2[e]] != 0) return "virtual-landmark edge " + std::to_string(e) + " must join two Se2 vertices";
+            ++deg_pose_od[cls[ev1[e]]]; ++deg_pose_od[cls[ev2[e]]];
+            ++pr.n_vlm_edges_total; pr.has_vlm = true;
         } else return "unknown edge type " + std::to_string(t);
     }
 
@@ -289,6 +299,19 @@ std::string build_problem(const tsgo_graph& g, const BuildOptions& opt, Problem&
                         double vals[LM_PLANES];
                         lm_static(m, w, vals);
                         for (int k = 0; k < LM_PLANES; ++k) { pr.by_pose.plane(k)[sp] = vals[k]; pr.by_lm.plane(k)[sl] = vals[k]; }
+                    }
+                } else if (g.e_type[e] == 2) {
+                    const int p1 = pose_internal[cls[ev1[e]]], p2 = pose_internal[cls[ev2[e]]];
+                    for (int side = 0; side < 2; ++side) {
+                        const int self = side ? p2 : p1, other = side ? p1 : p2;
+                        if (self < pr.pose_first || self >= pr.pose_last) continue;
+                        const size_t so = slot_of(pr.odom, self, fillO[self]++);
+                        pr.odom.idx[so] = (uint32_t)other | (side ? kDirBit : 0u) | kVlmBit;
+                        pr.odom.edge[so] = (uint32_t)e;
+                        if (opt.fill_planes) {
+                            double v9[9]; vlm_static(m, w, side, v9);
+                            for (int k = 0; k < 9; ++k) pr.odom.plane(k)[so] = v9[k];
+                        }
                     }
                 } else {
                     double inv[9];

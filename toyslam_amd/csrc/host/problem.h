@@ -24,6 +24,8 @@ namespace tsgo {
 
 constexpr uint32_t kNoEdge = 0xFFFFFFFFu;
 constexpr uint32_t kDirBit = 0x80000000u;   // odom slot: set when the row's pose is id2 of the edge
+constexpr uint32_t kVlmBit = 0x40000000u;   // odom slot: the edge is a virtual landmark measurement (edge type 2), not an ODOM edge
+constexpr uint32_t kPoseMask = 0x3FFFFFFFu; // odom slot: the neighbour's internal pose number
 constexpr int kWave = 64;
 constexpr double kGaugeTerm = 1e6;        // remote/optimizer/OptimizerCpu.h:136
 constexpr int kSortWindow = 2048;           // vertices; degree sort happens inside such windows
@@ -43,7 +45,8 @@ struct SellTable {
     const double* plane(int k) const { return planes.data() + (size_t)k * slots(); }
 };
 
-// LM tables: planes zx, zy, w0, w1.  ODOM table: planes mi[0..5], w[0..2].
+// LM tables: planes zx, zy, w0, w1.  ODOM table: planes mi[0..5], w[0..2]; a virtual-landmark slot (kVlmBit) keeps the local point of
+// its OWN pose and of the neighbour in mi[0..3] (pox, poy, pnx, pny) and its two weights in w[0..1].
 enum { LM_ZX = 0, LM_ZY, LM_W0, LM_W1, LM_PLANES };
 enum { OD_MI0 = 0, OD_W0 = 6, OD_PLANES = 9 };
 
@@ -63,6 +66,8 @@ struct Problem {
     std::vector<double> gauge_p, gauge_l;   // 1e6 * multiplicity in the fixed list: every pose (applied by the shard that owns it), owned landmarks
     SellTable by_pose, by_lm, odom;
     int n_vertices = 0;                 // of the input graph
+    bool has_vlm = false;               // the graph holds virtual landmark measurements (edge type 2): pose-pose slots in general form (tsgo_math.h)
+    int64_t n_vlm_edges_total = 0;
     bool odom_analytic = false;         // analytic ODOM Jacobians (tsgo_config.odom_jacobian): odometry then couples heading to translation,
                                         // so every pose an edge touches carries a lever arm in the multigrid coarse space (host/amg.cpp)
 };
@@ -84,5 +89,8 @@ bool invert3(const double* m, double* out);
 // diagonal — ONE definition, shared by build_problem and by the engine's staging/refill path, so that a refilled table
 // holds the same bits as a freshly built one.
 void lm_static(const double* meas, const double* inf, double* out4);
+// ... and the nine static plane values of a virtual-landmark slot at the edge's first (side = 0) or second endpoint:
+// meas = (r1, phi1, r2, phi2), inf = (w0, w1, .)
+void vlm_static(const double* meas, const double* inf, int side, double* out9);
 
 }  // namespace tsgo

@@ -102,10 +102,11 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
     T d[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // the odometry edges joining i and k: -diag(a) each, or the full H_12 / H_21 of the analytic Jacobians
     for (int q = optr[b]; q < optr[b + 1]; ++q) {
         const size_t e = oslot[q];
-        if (odom_analytic) {
-            const T k00 = od_dyn[e], k01 = od_dyn[od_slots + e], k11 = od_dyn[2 * od_slots + e], g0 = od_dyn[3 * od_slots + e], g1 = od_dyn[4 * od_slots + e], w = od_dyn[5 * od_slots + e];
-            d[0] -= k00; d[1] -= k01; d[3] -= k01; d[4] -= k11; d[8] -= w;
-            if (od_idx[e] & kDirMask) { d[2] += g0; d[5] += g1; } else { d[6] += g0; d[7] += g1; }      // row pose = second / first endpoint
+        if (odom_analytic) {      // general pose-pose slots (tsgo_math.h): the slot's own row block [[-K, c], [r^T, -kappa]]
+            T h[PP_PLANES];
+#pragma unroll
+            for (int m = 0; m < PP_PLANES; ++m) h[m] = od_dyn[(size_t)m * od_slots + e];
+            d[0] -= h[PP_K00]; d[1] -= h[PP_K01]; d[3] -= h[PP_K01]; d[4] -= h[PP_K11]; d[2] += h[PP_C0]; d[5] += h[PP_C1]; d[6] += h[PP_R0]; d[7] += h[PP_R1]; d[8] -= h[PP_KAPPA];
         } else { d[0] -= od_dyn[e]; d[4] -= od_dyn[od_slots + e]; d[8] -= od_dyn[2 * od_slots + e]; }
     }
 #pragma unroll

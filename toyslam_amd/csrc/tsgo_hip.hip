@@ -807,6 +807,11 @@ template <typename T> struct Engine : IEngine {
             for (size_t k = (size_t)b; k < (size_t)e; ++k) {
                 const uint32_t ed = pr.odom.edge[k];
                 if (ed == kNoEdge) { for (int m = 0; m < 9; ++m) dst[(size_t)m * So + k] = T(0); continue; }
+                if (pr.odom.idx[k] & kVlmBit) {      // virtual landmark measurement: the slot's own and the neighbour's local point, two weights
+                    double v9[9]; vlm_static(g.e_meas + 9 * (size_t)ed, g.e_inf + 3 * (size_t)ed, (pr.odom.idx[k] & kDirBit) ? 1 : 0, v9);
+                    for (int m = 0; m < 9; ++m) dst[(size_t)m * So + k] = (T)v9[m];
+                    continue;
+                }
                 double inv[9];
                 if (!invert3(g.e_meas + 9 * (size_t)ed, inv)) { int seen = bad_edge.load(); while ((int)ed < seen && !bad_edge.compare_exchange_weak(seen, (int)ed)) {} continue; }
                 for (int m = 0; m < 6; ++m) dst[(size_t)(OD_MI0 + m) * So + k] = (T)inv[m];
@@ -973,7 +978,7 @@ template <typename T> struct Engine : IEngine {
         const std::string err = build_problem(g, bo, pr);
         od_live = -1;
         if (!err.empty()) return set_error(-2, "tsgo_set_graph: " + err);
-        pr.odom_analytic = oj();
+        pr.odom_analytic = cfg.odom_jacobian == 1;
         const bool say = say_env;
         auto lap = [&, last = t0](const char* what) mutable {
             const auto n = std::chrono::steady_clock::now();
@@ -995,7 +1000,7 @@ template <typename T> struct Engine : IEngine {
         if (int rc = upload_T(&gauge_l, pr.gauge_l.data(), pr.gauge_l.size())) return rc;
         if (int rc = alloc_table(tp, &st_p, pr.by_pose, 4, 4, true)) return rc;
         if (int rc = alloc_table(tl, &st_l, pr.by_lm, 4, 4, true)) return rc;
-        if (int rc = alloc_table(to, &st_o, pr.odom, 9, oj() ? 6 : 3, false)) return rc;
+        if (int rc = alloc_table(to, &st_o, pr.odom, 9, oj() ? (int)PP_PLANES : 3, false)) return rc;
         if (int rc = stage_values(g, false)) return rc;
         // table-kernel grids are multiples of 8 (one eighth of the slices per XCD, see xcd_block())
         nbP = 8 * (((tp.n_slices + kWavesPerBlock - 1) / kWavesPerBlock + 7) / 8);
@@ -1083,17 +1088,20 @@ template <typename T> struct Engine : IEngine {
     // damping of the current linearisation (rules = 1, graph_optimizer.py:24-43; 0 under the cpu/eigen rules) and the step the update takes
     double lambda = 0;
     bool py_rules() const { return cfg.rules == 1; }
-    bool oj() const { return cfg.odom_jacobian == 1; }      // analytic ODOM Jacobians (tsgo_math.h: odom_blocks)
+    // pose-pose slots in general form (tsgo_math.h: eight dynamic planes per slot): analytic ODOM Jacobians, or a graph that holds
+    // virtual landmark measurements (edge type 2) — the kernels' OJ = 1 instantiations
+    bool oj() const { return cfg.odom_jacobian == 1 || pr.has_vlm; }
+    int odom_analytic_flag() const { return cfg.odom_jacobian == 1 ? 1 : 0; }
     double step_scale() const { return py_rules() ? cfg.lr : kStepScale; }
     void launch_lin() {
         const int zf = py_rules() ? 1 : 0;
         if (tl.n_slices > 0) LAUNCH_G(pr.by_lm.G, k_lin_lm, nbL, stream, tl, ps, lmrec, gauge_l, ninv, (T)lambda, zf);
-        if (oj()) LAUNCH_GM(pr.by_pose.G, k_lin_pose, 1, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
+        if (oj()) LAUNCH_GM(pr.by_pose.G, k_lin_pose, 1, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf, odom_analytic_flag());
         else LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
     }
     void launch_lin_pose_only() {       // tsgo_time_kernel
         const int zf = py_rules() ? 1 : 0;
-        if (oj()) LAUNCH_GM(pr.by_pose.G, k_lin_pose, 1, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
+        if (oj()) LAUNCH_GM(pr.by_pose.G, k_lin_pose, 1, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf, odom_analytic_flag());
         else LAUNCH_G(pr.by_pose.G, k_lin_pose, nbP, stream, tp, to, ps, lmrec, gauge_p, pr.pose_first, pr.pose_last, part, part + (size_t)pr.P * 18, (T)lambda, zf);
     }
     void launch_finalize() {

@@ -27,7 +27,9 @@ namespace tsgo {
 
 constexpr int kBlock = 256;             // threads per workgroup = 4 wavefronts
 constexpr int kWavesPerBlock = kBlock / 64;
-constexpr uint32_t kDirMask = 0x80000000u;
+constexpr uint32_t kDirMask = 0x80000000u;      // odom slot: the row's pose is the edge's second vertex
+constexpr uint32_t kVlmMask = 0x40000000u;      // odom slot: a virtual landmark measurement (edge type 2), general-pairs kernels only
+constexpr uint32_t kPoseIdxMask = 0x3FFFFFFFu;  // odom slot: the neighbour's internal pose number
 
 // record layouts (in units of T)
 constexpr int kPoseRec = 8;   // zc: v0 v1 v2 c s . . .      (the vector CG multiplies + the pose's cos/sin)
@@ -157,12 +159,14 @@ __global__ __launch_bounds__(kBlock) void k_lin_lm(Table<T> tb, const T* __restr
 // K2 lin_pose: per pose — pose-side linearisation of its LM edges + its ODOM rows.
 //   writes: slot planes (pose-major copy), ODOM weights, part[i][18] = Dp(6) g(3) Sd(6) Wu(3) in the
 //           world frame, one chi^2 partial per workgroup
-// OJ = 1: analytic ODOM Jacobians (tsgo_math.h: odom_blocks); the ODOM table then carries six dynamic planes (k00 k01 k11 g0 g1 w).
+// OJ = 1: pose-pose slots in GENERAL form (tsgo_math.h: eight dynamic planes per slot, the slot's own row block of the Hessian) — what
+// analytic ODOM Jacobians (odom_analytic, tsgo_config.odom_jacobian) and virtual landmark measurements (edge type 2, kVlmMask) need;
+// ODOM edges under the reference's constant Jacobians are written in that form too when the graph holds the other kind.
 template <typename T, int G, int OJ = 0>
 __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, const T* __restrict__ ps,
                                                      const T* __restrict__ lmrec, const T* __restrict__ gauge_p,
                                                      int pose_first, int pose_last, T* __restrict__ part,
-                                                     T* __restrict__ chi_part, T lambda, int zero_fixed) {
+                                                     T* __restrict__ chi_part, T lambda, int zero_fixed, int odom_analytic = 0) {
     __shared__ T red[kWavesPerBlock];
     const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
@@ -215,7 +219,7 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
                 const size_t k = (size_t)row * 64 + lane;
                 const uint32_t raw = od.idx[k];
                 const bool second = (raw & kDirMask) != 0;
-                const uint32_t j = raw & ~kDirMask;
+                const uint32_t j = raw & kPoseIdxMask;
                 T mi[6], w[3];
 #pragma unroll
                 for (int m = 0; m < 6; ++m) mi[m] = od.st[(size_t)m * S + k];
@@ -223,17 +227,35 @@ __global__ __launch_bounds__(kBlock) void k_lin_pose(Table<T> tb, Table<T> od, c
                 for (int m = 0; m < 3; ++m) w[m] = od.st[(size_t)(6 + m) * S + k];
                 const T* oq = ps + (size_t)j * 4;
                 const T xj = oq[0], yj = oq[1], cj = oq[2], sj = oq[3];
+                if (OJ && (raw & kVlmMask)) {      // virtual landmark measurement: mi = (pox, poy, pnx, pny, ., .), w = (w0, w1, .)
+                    const VlmLin<T> v = vlm_linearize<T>(x0, y0, c, s, xj, yj, cj, sj, mi[0], mi[1], mi[2], mi[3], w[0], w[1]);
+                    T h[PP_PLANES];
+                    vlm_slot<T>(v, h);
+#pragma unroll
+                    for (int m = 0; m < PP_PLANES; ++m) od.dyn[(size_t)m * S + k] = h[m];
+                    od0 += v.om0; od1 += v.om1; od02 += v.om0 * v.u0; od12 += v.om1 * v.u1; od2 += v.om0 * v.u0 * v.u0 + v.om1 * v.u1 * v.u1;
+                    og0 -= v.om0 * v.d0; og1 -= v.om1 * v.d1; og2 -= v.om0 * v.u0 * v.d0 + v.om1 * v.u1 * v.d1;
+                    if (!second) chi += v.rho;
+                    continue;
+                }
                 const OdomLin<T> o = second ? odom_linearize<T>(xj, yj, cj, sj, x0, y0, c, s, mi, w)
                                             : odom_linearize<T>(x0, y0, c, s, xj, yj, cj, sj, mi, w);
-                if (OJ) {
+                if (OJ && odom_analytic) {
                     const OdomBlocks<T> ob = second ? odom_blocks<T>(o, xj, yj, cj, sj, x0, y0, c, s, mi) : odom_blocks<T>(o, x0, y0, c, s, xj, yj, cj, sj, mi);
-                    od.dyn[k] = ob.k00; od.dyn[S + k] = ob.k01; od.dyn[2 * S + k] = ob.k11;
-                    od.dyn[3 * S + k] = ob.g0; od.dyn[4 * S + k] = ob.g1; od.dyn[5 * S + k] = ob.w;
+                    // H_12 = [[-K, 0], [g^T, -w]] at the first endpoint, its transpose at the second
+                    od.dyn[(size_t)PP_K00 * S + k] = ob.k00; od.dyn[(size_t)PP_K01 * S + k] = ob.k01; od.dyn[(size_t)PP_K11 * S + k] = ob.k11;
+                    od.dyn[(size_t)PP_C0 * S + k] = second ? ob.g0 : T(0); od.dyn[(size_t)PP_C1 * S + k] = second ? ob.g1 : T(0);
+                    od.dyn[(size_t)PP_R0 * S + k] = second ? T(0) : ob.g0; od.dyn[(size_t)PP_R1 * S + k] = second ? T(0) : ob.g1;
+                    od.dyn[(size_t)PP_KAPPA * S + k] = ob.w;
                     od0 += ob.k00; od01 += ob.k01; od1 += ob.k11;
                     if (!second) { od02 -= ob.g0; od12 -= ob.g1; od2 += ob.s + ob.w; og0 += ob.h0; og1 += ob.h1; og2 += ob.kt - ob.ht; }
                     else { od2 += ob.w; og0 -= ob.h0; og1 -= ob.h1; og2 -= ob.kt; }
                 } else {
-                    od.dyn[k] = o.a[0]; od.dyn[S + k] = o.a[1]; od.dyn[2 * S + k] = o.a[2];
+                    if (OJ) {      // the reference's constants in the general form: K = diag(a0, a1), c = r = 0, kappa = a2
+                        od.dyn[(size_t)PP_K00 * S + k] = o.a[0]; od.dyn[(size_t)PP_K01 * S + k] = T(0); od.dyn[(size_t)PP_K11 * S + k] = o.a[1];
+                        od.dyn[(size_t)PP_C0 * S + k] = T(0); od.dyn[(size_t)PP_C1 * S + k] = T(0); od.dyn[(size_t)PP_R0 * S + k] = T(0); od.dyn[(size_t)PP_R1 * S + k] = T(0);
+                        od.dyn[(size_t)PP_KAPPA * S + k] = o.a[2];
+                    } else { od.dyn[k] = o.a[0]; od.dyn[S + k] = o.a[1]; od.dyn[2 * S + k] = o.a[2]; }
                     od0 += o.a[0]; od1 += o.a[1]; od2 += o.a[2];
                     const T sg = second ? T(-1) : T(1);
                     og0 += sg * o.a[0] * o.e[0]; og1 += sg * o.a[1] * o.e[1]; og2 += sg * o.a[2] * o.e[2];
@@ -472,15 +494,15 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
             for (uint32_t row = r0; row < r1; ++row) {
                 const size_t k = (size_t)row * 64 + lane;
                 const uint32_t raw = od.idx[k];
-                const uint32_t j = raw & ~kDirMask;
+                const uint32_t j = raw & kPoseIdxMask;
                 T zj[3];
                 if (LOW) { const float* q = zc32 + (size_t)j * kPoseRec; zj[0] = q[0]; zj[1] = q[1]; zj[2] = q[2]; }
                 else { const T* q = zc + (size_t)j * kPoseRec; zj[0] = q[0]; zj[1] = q[1]; zj[2] = q[2]; }
-                if (OJ) {           // H_12 = [[-K, 0], [g^T, -w]] seen from the first endpoint, its transpose from the second
-                    const T k00 = od.dyn[k], k01 = od.dyn[S + k], k11 = od.dyn[2 * S + k], g0 = od.dyn[3 * S + k], g1 = od.dyn[4 * S + k], w = od.dyn[5 * S + k];
-                    const T zt0 = zj[0], zt1 = zj[1], zth = zj[2];
-                    o0 -= k00 * zt0 + k01 * zt1; o1 -= k01 * zt0 + k11 * zt1; o2 -= w * zth;
-                    if (raw & kDirMask) { o0 += g0 * zth; o1 += g1 * zth; } else o2 += g0 * zt0 + g1 * zt1;
+                if (OJ) {           // the slot's own row block H_pn = [[-K, c], [r^T, -kappa]] (tsgo_math.h), whatever edge it came from
+                    T h[PP_PLANES];
+#pragma unroll
+                    for (int m = 0; m < PP_PLANES; ++m) h[m] = od.dyn[(size_t)m * S + k];
+                    pair_apply<T>(h, zj[0], zj[1], zj[2], o0, o1, o2);
                 } else { o0 -= od.dyn[k] * zj[0]; o1 -= od.dyn[S + k] * zj[1]; o2 -= od.dyn[2 * S + k] * zj[2]; }
             }
         }

@@ -105,6 +105,53 @@ TSGO_HD OdomLin<T> odom_linearize(T x1, T y1, T c1, T s1, T x2, T y2, T c2, T s2
     return o;
 }
 
+// ---- pose-pose slots in general form -------------------------------------------------------------------------------------------
+// A pose-pose edge is listed at BOTH endpoints; the slot at pose p (neighbour n) carries ITS row block of the Hessian,
+//     H_pn = [[-K, c], [r^T, -kappa]]        K symmetric 2x2 (k00 k01 k11), c and r 2-vectors, kappa scalar: 8 numbers,
+// already oriented for p, so that the passes that use it (the Schur product of a pose row, the explicit level-0 block) need not
+// know what kind of edge it came from:
+//     constant ODOM Jacobians (EdgeSe2.h:35-37)   K = diag(a0, a1), c = r = 0, kappa = a2
+//     analytic ODOM Jacobians, p the first pose   K, c = 0, r = g, kappa = w          (H_12 = [[-K, 0], [g^T, -w]], above)
+//                              p the second pose  K, c = g, r = 0, kappa = w          (H_21 = H_12^T)
+//     virtual landmark measurement                K = Omega, c = -Omega v, r = -Omega u, kappa = u^T Omega v     (below)
+// The 8-plane layout is what kernels built for `general pairs` (k_lin_pose<.., 1>, k_schur_pose<.., 1>, k_schur_blocks) use.
+enum { PP_K00 = 0, PP_K01, PP_K11, PP_C0, PP_C1, PP_R0, PP_R1, PP_KAPPA, PP_PLANES };
+template <typename T> struct PairSlot { T v[PP_PLANES]; };
+
+// out_p += H_pn z_n
+template <typename T> TSGO_HD void pair_apply(const T* h, T z0, T z1, T zt, T& o0, T& o1, T& o2) {
+    o0 += -(h[PP_K00] * z0 + h[PP_K01] * z1) + h[PP_C0] * zt;
+    o1 += -(h[PP_K01] * z0 + h[PP_K11] * z1) + h[PP_C1] * zt;
+    o2 += h[PP_R0] * z0 + h[PP_R1] * z1 - h[PP_KAPPA] * zt;
+}
+
+// Virtual landmark measurement (edge type 2; python/optimizer/edges2d.py:83-121, restated in oracle/oracle_dense.cpp: vlm_edge): the
+// same physical point seen from two poses, e = T1 p1 - T2 p2, A = [I | dR1/dth p1], B = -[I | dR2/dth p2].  Seen from the slot's OWN
+// pose (x, y, c, s; local point (pox, poy)) with the neighbour (xn, yn, cn, sn; (pnx, pny)):
+//   d = own world point - neighbour's world point  (= e at the first endpoint, -e at the second),  u = dR_own/dth p_own,  v = dR_n/dth p_n
+//   J_own^T Omega (signed residual) = [I | u]^T Omega d,   H_pp += [I | u]^T Omega [I | u],   H_pn = -[I | u]^T Omega [I | v]
+// with Omega = Huber weight * diag(w0, w1) — no direction bit needed beyond counting chi^2 once.
+template <typename T> struct VlmLin { T om0, om1, u0, u1, v0, v1, d0, d1, rho; };
+template <typename T>
+TSGO_HD VlmLin<T> vlm_linearize(T x, T y, T c, T s, T xn, T yn, T cn, T sn, T pox, T poy, T pnx, T pny, T w0, T w1) {
+    VlmLin<T> o;
+    o.d0 = (x + c * pox - s * poy) - (xn + cn * pnx - sn * pny);
+    o.d1 = (y + s * pox + c * poy) - (yn + sn * pnx + cn * pny);
+    o.u0 = -s * pox - c * poy; o.u1 = c * pox - s * poy;
+    o.v0 = -sn * pnx - cn * pny; o.v1 = cn * pnx - sn * pny;
+    const T chi2 = w0 * o.d0 * o.d0 + w1 * o.d1 * o.d1;
+    T hw;
+    huber(chi2, o.rho, hw);
+    o.om0 = hw * w0; o.om1 = hw * w1;
+    return o;
+}
+template <typename T> TSGO_HD void vlm_slot(const VlmLin<T>& o, T* h) {
+    h[PP_K00] = o.om0; h[PP_K01] = T(0); h[PP_K11] = o.om1;
+    h[PP_C0] = -o.om0 * o.v0; h[PP_C1] = -o.om1 * o.v1;
+    h[PP_R0] = -o.om0 * o.u0; h[PP_R1] = -o.om1 * o.u1;
+    h[PP_KAPPA] = o.om0 * o.u0 * o.v0 + o.om1 * o.u1 * o.v1;
+}
+
 // Symmetric 2x2 inverse (xx, xy, yy).  A singular block (vertex without edges) maps to zero, which
 // leaves that vertex where it is (the reference's rank-revealing QR does the same).
 template <typename T> TSGO_HD void inv_sym2(T xx, T xy, T yy, T& ixx, T& ixy, T& iyy) {

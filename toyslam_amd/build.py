@@ -24,7 +24,7 @@ def _newer(target, sources):
 def _all_sources():
     out = []
     for root, _d, files in os.walk(CSRC):
-        out += [os.path.join(root, f) for f in files if f.endswith((".h", ".hip", ".cpp"))]
+        out += [os.path.join(root, f) for f in files if f.endswith((".h", ".hip", ".cpp", ".inc"))]
     out.append(os.path.join(os.path.dirname(HERE), "include", "tsgo.h"))
     out.append(os.path.join(os.path.dirname(HERE), "include", "tsgo_testing.h"))
     return out

@@ -381,6 +381,11 @@ __global__ __launch_bounds__(kBlock) void k_to_planes(int n_rows, const int* __r
 // length of the dependent-load chain, so LPR lanes share one block row (one 3x3 block per lane per
 // trip, 72 contiguous bytes per lane) and finish with an LPR-lane xor-shuffle sum.
 
+// Block-row kernels of the big levels take the XCD-aware workgroup map of the table kernels (xcd_block(), tsgo_kernels.h): an XCD walks a
+// contiguous eighth of the rows, so the vector entries a row gathers (its neighbours': nearby rows) are fetched into ONE L2 instead of all
+// eight (PMC, round 3: k_restrict from level 0 fetched 1.74x its algorithmic bytes, k_prolong_add 1.48x).  xcd = 0: round-robin, as before.
+__device__ __forceinline__ int lpr_block(int xcd) { return xcd ? xcd_block() : (int)blockIdx.x; }
+
 // MODE 0: out = r - A z.   MODE 1: out = z + omega Dinv (r - A z)  (smoothing sweep).
 // MODE 2: out = Dinv A z  (power iteration for the smoother's damping).
 // PM: A is the cycle-format copy (above; PK = its encoding); otherwise the block-indexed f32 / HT matrix.
@@ -388,9 +393,9 @@ template <typename T, int LPR, int MODE, int PM = 1, int PK = 0>
 __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __restrict__ ptr, const int* __restrict__ col,
                                                           const void* __restrict__ Av, const T* __restrict__ r, const T* __restrict__ z,
                                                           const HT<T>* __restrict__ Dinv, T* __restrict__ out,
-                                                          const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
+                                                          const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st, int xcd = 0) {
     const int done = MODE != 2 ? st->done : 0;
-    const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
+    const int g = (lpr_block(xcd) * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     // LPR == 64: the row is wave-uniform, its bounds come through the scalar cache (one dependent round trip shorter)
     const int i = LPR == 64 ? __builtin_amdgcn_readfirstlane(g < n ? g : n - 1) : (g < n ? g : n - 1);
     T s0 = 0, s1 = 0, s2 = 0;
@@ -450,9 +455,9 @@ __global__ __launch_bounds__(kBlock) void k_bcsr_residual(int n, const int* __re
 // implicit Schur product inside the cycle; z is the pose-record array zc, stride kPoseRec).  A plane-major (cycle format).
 template <typename T, int LPR, int PK>
 __global__ __launch_bounds__(kBlock) void k_bcsr_apply(int n, const int* __restrict__ ptr, const int* __restrict__ col, const uint32_t* __restrict__ A,
-                                                       const T* __restrict__ z, int zs, T* __restrict__ out, const CgState<T>* __restrict__ st) {
+                                                       const T* __restrict__ z, int zs, T* __restrict__ out, const CgState<T>* __restrict__ st, int xcd = 0) {
     const int done = st->done;
-    const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
+    const int g = (lpr_block(xcd) * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
     int p0 = ptr[i];
@@ -478,9 +483,9 @@ template <typename T, int LPR, int SUB, int PK = 0>
 __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __restrict__ rptr, const int* __restrict__ rcol,
                                                      const uint32_t* __restrict__ Rv, const T* __restrict__ va,
                                                      const T* __restrict__ vb, T* __restrict__ rc, const HT<T>* __restrict__ dinv_next,
-                                                     T* __restrict__ z_next, const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st) {
+                                                     T* __restrict__ z_next, const T* __restrict__ omega_ptr, const CgState<T>* __restrict__ st, int xcd = 0) {
     const int done = st->done;
-    const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
+    const int g = (lpr_block(xcd) * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int a = g < n_agg ? g : n_agg - 1;
     T s0 = 0, s1 = 0, s2 = 0;
     int p0 = rptr[a];
@@ -520,9 +525,9 @@ __global__ __launch_bounds__(kBlock) void k_restrict(int n_agg, const int* __res
 template <typename T, int LPR, int PK = 0>
 __global__ __launch_bounds__(kBlock) void k_prolong_add(int n, const int* __restrict__ pptr, const int* __restrict__ pcol,
                                                         const uint32_t* __restrict__ P, const T* __restrict__ e, T* __restrict__ z, int zs,
-                                                        const CgState<T>* __restrict__ st, float* __restrict__ z32 = nullptr) {
+                                                        const CgState<T>* __restrict__ st, float* __restrict__ z32 = nullptr, int xcd = 0) {
     const int done = st->done;
-    const int g = (blockIdx.x * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
+    const int g = (lpr_block(xcd) * kBlock + threadIdx.x) / LPR, sub = threadIdx.x % LPR;
     const int i = g < n ? g : n - 1;
     T s0 = 0, s1 = 0, s2 = 0;
     int p0 = pptr[i];

@@ -3,7 +3,8 @@ the CPU twin (tight tolerances on both).  Exercises warm start, lagged hierarchy
 round 2: every 4th graph with the analytic ODOM Jacobians, every 5th under the Python optimizer's rules (lambda * I, random
 lr), every 3rd sent again to the same handle (structure reuse: bit-identical answer); round 3: every 3rd (+1) goes to a handle with
 tsgo_config.warm_requests and comes back with the returned estimates (f32, as over the wire): that second request, started from the
-first one's solver history — kept for this structure, or carried over from whatever graph the handle held before — against the twin."""
+first one's solver history — kept for this structure, or carried over from whatever graph the handle held before — against the twin;
+round 4: every 6th (+4) landmark graph carries virtual landmark measurements (edge type 2: the general pose-pose slots)."""
 import sys, time
 import numpy as np
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
@@ -30,6 +31,9 @@ while time.time() < t_end:
         keep = g.e_type == 0; pose = g.v_type == 0
         g = GraphArrays(g.v_id[pose], g.v_type[pose], g.v_pos[pose], g.e_type[keep], g.e_ids[keep], g.e_meas[keep], g.e_inf[keep], g.fixed)
         shape = "pose graph"
+    if trial % 6 == 4 and shape == "landmarks":      # round 4: virtual landmark measurements (edge type 2) mixed in, sometimes in place of the LM edges they came from
+        g = util.with_virtual_landmarks(g, float(rng.choice([0.2, 0.5, 0.9])), seed=int(rng.integers(0, 10 ** 6)), keep_lm=bool(rng.integers(0, 2)))
+        shape = "landmarks+vlm%d" % int((g.e_type == 2).sum())
     fx = [0] + [int(v) for v in rng.choice(g.v_id, size=int(rng.integers(0, 3)), replace=False)]
     g.fixed = np.array(fx, np.uint32)
     oj = "analytic" if trial % 4 == 1 else "constant"
@@ -100,7 +104,7 @@ while time.time() < t_end:
     ok = r["iters"] == ref["iters"] and r["stop"] == ref["stop"] and np.allclose(r["chi2"], ref["chi2"], rtol=1e-6 if (diverging or beam) else 1e-8) \
         and (diverging or d < (1e-4 if beam else bar))      # a diverging run (chi^2 rising; seed 51 trial 87: 1.1e4 -> 9.5e6 under full steps) is compared by its chi^2: two device runs at 1e-11 / 1e-13 end 1e-3 apart (profiles/r03y_soak_trial87_replay.log)
     worst = max(worst, d); most_cg = max(most_cg, int(max(r["cg_iters"]))); fallbacks += int(r["fallbacks"])
-    print("trial %3d %-18s n=%6d k=%2d closures=%4d fixed=%d: GN %d/%d stop %s/%s  cg %s  max vertex diff %.2e  %s"
+    print("trial %3d %-22s n=%6d k=%2d closures=%4d fixed=%d: GN %d/%d stop %s/%s  cg %s  max vertex diff %.2e  %s"
           % (trial, shape, n, k, lc, len(fx), r["iters"], ref["iters"], r["stop"], ref["stop"], list(map(int, r["cg_iters"])), d, "ok" if ok else "MISMATCH"), flush=True)
     if not ok:
         sys.exit(1)

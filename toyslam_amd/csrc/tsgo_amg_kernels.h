@@ -48,6 +48,33 @@ template <typename T> __device__ __forceinline__ void m3_inv(const T* m, T* o) {
     o[6] = c02 * r; o[7] = (m[1] * m[6] - m[0] * m[7]) * r; o[8] = (m[0] * m[4] - m[1] * m[3]) * r;
 }
 
+// cycle format (described further down, "cycle format"): words per 3x3 block, and the packing of one block
+constexpr int kCyWordsF32 = 9, kCyWordsF16 = 5;
+template <int PK> __host__ __device__ constexpr int cy_words() { return PK ? kCyWordsF16 : kCyWordsF32; }
+// the nine values of one block into its cycle-format words (the j-th block of a row of `len` blocks whose words start at `o` = base + j)
+template <int PK> __device__ __forceinline__ void cy_store(const float* v, uint32_t* __restrict__ o, size_t len) {
+    if (PK) {
+        float mx = 0;
+#pragma unroll
+        for (int m = 0; m < 9; ++m) mx = fmaxf(mx, fabsf(v[m]));
+        int e = 0;
+        if (mx > 0.f && mx < 3.0e38f) {
+            e = ilogbf(mx) - 14;                                  // largest entry -> [2^14, 2^15)
+            e = e < -126 ? -126 : (e > 112 ? 112 : e);            // 2^e and 2^-e stay normal floats
+        }
+        const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
+        unsigned short h[9];
+#pragma unroll
+        for (int m = 0; m < 9; ++m) h[m] = __half_as_ushort(__float2half_rn(v[m] * inv));
+#pragma unroll
+        for (int m = 0; m < 4; ++m) o[(size_t)m * len] = (uint32_t)h[2 * m] | ((uint32_t)h[2 * m + 1] << 16);
+        o[(size_t)4 * len] = (uint32_t)h[8] | ((uint32_t)(unsigned short)(short)e << 16);
+    } else {
+#pragma unroll
+        for (int m = 0; m < 9; ++m) o[(size_t)m * len] = __float_as_uint(v[m]);
+    }
+}
+
 // ---- numeric setup ---------------------------------------------------------------------------------
 // Explicit Schur complement blocks S_ik (level 0 of the hierarchy), one thread per block on or above the diagonal.
 //   diagonal: Dp - Sd from the linearisation partials; off-diagonal: -sum_j W_ij N_j W_kj^T - odom.
@@ -136,11 +163,15 @@ __global__ __launch_bounds__(kBlock) void k_block_inv(int n, const int* __restri
 }
 
 // P = Z - w Dinv (A Z), one thread per P block; Z_k = [[1,0,-ry],[0,1,rx],[0,0,1]] (rigid modes).
-template <typename T>
+// PK: also writes the cycle-format words of the block in P's rows (Ppm) and, transposed, in R's rows (Rpm) — what k_to_planes did in two more
+// launches per level.
+template <typename T, int PK>
 __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __restrict__ p_row, const int* __restrict__ p_self,
                                                         const int* __restrict__ sptr, const int* __restrict__ sx, const int* __restrict__ sy,
                                                         const HT<T>* __restrict__ A, const HT<T>* __restrict__ Dinv, const T* __restrict__ rel,
-                                                        T omega, HT<T>* __restrict__ P, const int* __restrict__ p_to_r, HT<T>* __restrict__ Rv) {
+                                                        T omega, HT<T>* __restrict__ P, const int* __restrict__ p_to_r, HT<T>* __restrict__ Rv,
+                                                        const int* __restrict__ p_ptr, const int* __restrict__ p_col, const int* __restrict__ r_ptr,
+                                                        uint32_t* __restrict__ Ppm, uint32_t* __restrict__ Rpm) {
     const int pb = blockIdx.x * kBlock + threadIdx.x;
     if (pb >= nnzP) return;
     const int i = p_row[pb];
@@ -168,11 +199,19 @@ __global__ __launch_bounds__(kBlock) void k_prolongator(int nnzP, const int* __r
     for (int m = 0; m < 9; ++m) P[(size_t)pb * 9 + m] = o[m];
     // the same block transposed, stored in the order the restriction walks it (rows of R = P^T):
     // reading P through an index there cost 2.7x the bytes (profiles/r01c: 88 MB for a 33 MB operator)
-    HT<T>* rt = Rv + (size_t)p_to_r[pb] * 9;
+    const int rb = p_to_r[pb];
+    HT<T>* rt = Rv + (size_t)rb * 9;
+    float vp[9], vr[9];
 #pragma unroll
     for (int i = 0; i < 3; ++i)
 #pragma unroll
-        for (int j = 0; j < 3; ++j) rt[3 * i + j] = o[3 * j + i];
+        for (int j = 0; j < 3; ++j) { rt[3 * i + j] = o[3 * j + i]; vp[3 * i + j] = (float)(HT<T>)o[3 * i + j]; vr[3 * i + j] = (float)(HT<T>)o[3 * j + i]; }
+    {
+        const int p0 = p_ptr[i];
+        cy_store<PK>(vp, Ppm + (size_t)p0 * cy_words<PK>() + (pb - p0), (size_t)(p_ptr[i + 1] - p0));
+        const int a = p_col[pb], q0 = r_ptr[a];
+        cy_store<PK>(vr, Rpm + (size_t)q0 * cy_words<PK>() + (rb - q0), (size_t)(r_ptr[a + 1] - q0));
+    }
 }
 
 // out[o] = sum over its pair list of X[x] * Y[y]  (TRANS: X[x]^T * Y[y]).  Three lanes per output block, one per
@@ -307,8 +346,7 @@ __global__ __launch_bounds__(kDenseThreads) void k_dense_inverse(int nb, const i
 //           every use inside the cycle (pre-sweeps, residual, post-sweeps; restriction and prolongation through R = P^T copies of
 //           the same rounded blocks) reads THIS copy, the V-cycle stays a symmetric operator.  The setup (Galerkin products,
 //           diagonal inverses) keeps the f32 blocks.
-constexpr int kCyWordsF32 = 9, kCyWordsF16 = 5;
-template <int PK> __host__ __device__ constexpr int cy_words() { return PK ? kCyWordsF16 : kCyWordsF32; }
+// (kCyWordsF32 / kCyWordsF16, cy_words<PK>() and cy_store<PK>() are defined at the top of this file: the set-up kernels write the format too)
 
 // the j-th block of a row whose cycle-format words start at `base` (row length len): its words as stored (cy_fetch: loads only, so
 // that several blocks' words can be requested before any is used), and the words as nine values of type T (cy_decode)
@@ -350,26 +388,38 @@ __global__ __launch_bounds__(kBlock) void k_to_planes(int n_rows, const int* __r
         float v[9];
 #pragma unroll
         for (int m = 0; m < 9; ++m) v[m] = (float)b[m];
-        if (PK) {
-            float mx = 0;
+        cy_store<PK>(v, o, (size_t)len);
+    }
+}
+
+// Round 4: the cycle-format copies are written by the kernels that PRODUCE the blocks — k_prolongator (P and R = P^T) and k_mirror_pack
+// (the Galerkin matrix of the next level) — instead of by fourteen k_to_planes launches per hierarchy build (137 us at 100k poses).
+// k_to_planes remains for the explicit level-0 matrix of tsgo_config.cycle_level0 = 1.
+//
+// The Galerkin product P^T (A P) is symmetric: only its blocks on and above the diagonal are summed from pair lists; a block below it is
+// the transpose of its mirror (host/amg.h: a_mirror).  One thread per block: fills the mirrored block and writes the block's
+// cycle-format words (row = the block's row, ptr = the matrix's row pointers).
+template <typename T, int PK>
+__global__ __launch_bounds__(kBlock) void k_mirror_pack(int n_blocks, const int* __restrict__ mirror, HT<T>* __restrict__ A, const int* __restrict__ row,
+                                                        const int* __restrict__ ptr, uint32_t* __restrict__ Apm) {
+    const int b = blockIdx.x * kBlock + threadIdx.x;
+    if (b >= n_blocks) return;
+    const int m = mirror[b];
+    float v[9];
+    if (m >= 0) {
 #pragma unroll
-            for (int m = 0; m < 9; ++m) mx = fmaxf(mx, fabsf(v[m]));
-            int e = 0;
-            if (mx > 0.f && mx < 3.0e38f) {
-                e = ilogbf(mx) - 14;                                  // largest entry -> [2^14, 2^15)
-                e = e < -126 ? -126 : (e > 112 ? 112 : e);            // 2^e and 2^-e stay normal floats
-            }
-            const float inv = __uint_as_float((uint32_t)(127 - e) << 23);
-            unsigned short h[9];
+        for (int x = 0; x < 3; ++x)
 #pragma unroll
-            for (int m = 0; m < 9; ++m) h[m] = __half_as_ushort(__float2half_rn(v[m] * inv));
+            for (int y = 0; y < 3; ++y) v[3 * x + y] = (float)A[(size_t)m * 9 + 3 * y + x];
 #pragma unroll
-            for (int m = 0; m < 4; ++m) o[(size_t)m * len] = (uint32_t)h[2 * m] | ((uint32_t)h[2 * m + 1] << 16);
-            o[(size_t)4 * len] = (uint32_t)h[8] | ((uint32_t)(unsigned short)(short)e << 16);
-        } else {
+        for (int k = 0; k < 9; ++k) A[(size_t)b * 9 + k] = v[k];
+    } else {
 #pragma unroll
-            for (int m = 0; m < 9; ++m) o[(size_t)m * len] = __float_as_uint(v[m]);
-        }
+        for (int k = 0; k < 9; ++k) v[k] = (float)A[(size_t)b * 9 + k];
+    }
+    if (Apm) {
+        const int i = row[b], p0 = ptr[i];
+        cy_store<PK>(v, Apm + (size_t)p0 * cy_words<PK>() + (b - p0), (size_t)(ptr[i + 1] - p0));
     }
 }
 

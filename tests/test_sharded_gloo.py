@@ -28,7 +28,14 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, out_dir, n_poses, precond, rules, explicit_cycle=False):
+def _graph(n_poses, vlm):
+    from tests import util
+    from toyslam_amd import synth
+    g = synth.make(n_poses, 10, loop_closures=30, seed=11)
+    return util.with_virtual_landmarks(g, 0.4, seed=3) if vlm else g      # round 4: virtual landmark measurements (edge type 2) ride in the ODOM rows a shard owns
+
+
+def _worker(rank, world, port, out_dir, n_poses, precond, rules, explicit_cycle=False, vlm=False):
     sys.path.insert(0, ROOT)
     torch.set_num_threads(2 if world <= 3 else 1)      # also sizes the twin's OpenMP loops (same libgomp); eight ranks share this box's eight CPUs
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
@@ -37,7 +44,7 @@ def _worker(rank, world, port, out_dir, n_poses, precond, rules, explicit_cycle=
     from tests import util
     from toyslam_amd import synth
     oracle.set_cycle_level0("explicit" if explicit_cycle else "implicit")       # the twin's side of tsgo_config.cycle_level0
-    g = synth.make(n_poses, 10, loop_closures=30, seed=11)
+    g = _graph(n_poses, vlm)
     calls = [0]
 
     def allreduce(buf):
@@ -57,13 +64,13 @@ def _worker(rank, world, port, out_dir, n_poses, precond, rules, explicit_cycle=
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,precond,n_poses,rules", [(2, "jacobi", 300, "cpp"), (2, "amg", 1500, "cpp"), (3, "amg", 700, "cpp"), (2, "amg", 600, "python"), (8, "amg", 2400, "cpp")])
-def test_sharded_run_across_processes_matches_single_process(tmp_path, world, precond, n_poses, rules):
-    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_poses, precond, rules), nprocs=world, join=True)
+@pytest.mark.parametrize("world,precond,n_poses,rules,vlm", [(2, "jacobi", 300, "cpp", False), (2, "amg", 1500, "cpp", False), (3, "amg", 700, "cpp", False), (2, "amg", 600, "python", False),
+                                                             (8, "amg", 2400, "cpp", False), (2, "amg", 900, "cpp", True)])
+def test_sharded_run_across_processes_matches_single_process(tmp_path, world, precond, n_poses, rules, vlm):
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path), n_poses, precond, rules, False, vlm), nprocs=world, join=True)
     from oracle import oracle
     from tests import util
-    from toyslam_amd import synth
-    g = synth.make(n_poses, 10, loop_closures=30, seed=11)
+    g = _graph(n_poses, vlm)
     ref = oracle.sparse_optimize(util.to_oracle(g), 3, pcg_tol=1e-12, precond=precond, rules=rules, lr=0.5)
     outs = [np.load(os.path.join(str(tmp_path), "rank%d.npz" % r)) for r in range(world)]
     for o in outs:

@@ -1013,7 +1013,8 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
 }
 
 // First kernel of every multigrid-preconditioned PCG iteration, one workgroup: has the residual the last k_cg_step produced met the
-// stopping rule?  Then this and every later kernel of the solve exits at once (they all read st->done).
+// stopping rule?  (Round 4: on the default path the test rides in workgroup 0 of the iteration's first product kernel instead —
+// iter_gate_body in tsgo_kernels.h, k_schur_lm's `gate` argument — and this kernel runs only where that product is not the first launch.)  Then this and every later kernel of the solve exits at once (they all read st->done).
 // host_flag (pinned host memory, eager launches only): the gate of the seq-th launched iteration tells the host thread that it has
 // run and what it saw — one 64-bit word: seq | done | fail | iterations completed — so that the host
 // neither predicts how many iterations a solve will take nor drains the stream to find out (Engine::do_solve_paced).
@@ -1021,19 +1022,7 @@ template <typename T>
 __global__ __launch_bounds__(kBlock) void k_iter_gate(CgState<T>* __restrict__ st, const T* __restrict__ rdr_part, const T* __restrict__ bpart, int n, T tol2,
                                                       int* __restrict__ host_flag, int seq) {
     __shared__ T red[kWavesPerBlock];
-    const int done = st->done, iters = st->iters, fail0 = st->fail;
-    T a = 0, b = 0;                                  // the partials are on their way while the state is looked at
-    for (int k = threadIdx.x; k < n; k += kBlock) { a += rdr_part[k]; b += bpart[k]; }
-    issue_before_exit(a);
-    int done_now = done, fail_now = fail0;
-    if (!(done || iters == 0)) {                     // iteration 0: no step has been taken yet (a warm start is judged by k_warm_scale)
-        const T rdr = block_sum<T>(a, red);
-        const T bdb = block_sum<T>(b, red);
-        if (threadIdx.x == 0 && !(rdr > tol2 * bdb)) { fail_now = (rdr != rdr) ? 1 : 0; done_now = 1; st->done = 1; st->fail = fail_now; }      // NaN: breakdown
-    }
-    if (host_flag && threadIdx.x == 0)      // ONE aligned 8-byte store: the host never sees the fields of two gates mixed
-        *reinterpret_cast<volatile unsigned long long*>(host_flag) =
-            ((unsigned long long)(unsigned)seq << 32) | ((unsigned long long)(done_now ? 1u : 0u) << 31) | ((unsigned long long)((unsigned)fail_now & 7u) << 28) | (unsigned long long)((unsigned)iters & 0x0fffffffu);
+    iter_gate_body<T>(GateArgs<T>{st, rdr_part, bpart, n, tol2, host_flag, seq}, red);
 }
 
 }  // namespace tsgo

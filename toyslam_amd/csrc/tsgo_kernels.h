@@ -105,6 +105,27 @@ template <typename T> __device__ __forceinline__ T block_sum_array(const T* a, i
     return block_sum(v, red);
 }
 
+// The stopping rule of the multigrid-preconditioned PCG, evaluated by ONE workgroup at the start of an iteration (tsgo_amg_kernels.h:
+// k_iter_gate, or workgroup 0 of the iteration's first product kernel): sums the partials of r^T D^-1 r (left by k_cg_step) and of
+// b^T D^-1 b, sets st->done when the residual meets the tolerance, and — eager launches — tells the host thread in ONE aligned 8-byte
+// store that the seq-th launched iteration has started and what it saw (seq | done | fail | iterations completed; Engine::do_solve_paced).
+template <typename T> struct GateArgs { CgState<T>* st; const T* rdr_part; const T* bpart; int n; T tol2; int* host_flag; int seq; };
+template <typename T> __device__ __forceinline__ void iter_gate_body(const GateArgs<T> g, T* red) {
+    const int done = g.st->done, iters = g.st->iters, fail0 = g.st->fail;
+    T a = 0, b = 0;                                  // the partials are on their way while the state is looked at
+    for (int k = threadIdx.x; k < g.n; k += kBlock) { a += g.rdr_part[k]; b += g.bpart[k]; }
+    issue_before_exit(a);
+    int done_now = done, fail_now = fail0;
+    if (!(done || iters == 0)) {                     // iteration 0: no step has been taken yet (a warm start is judged by k_warm_scale)
+        const T rdr = block_sum<T>(a, red);
+        const T bdb = block_sum<T>(b, red);
+        if (threadIdx.x == 0 && !(rdr > g.tol2 * bdb)) { fail_now = (rdr != rdr) ? 1 : 0; done_now = 1; g.st->done = 1; g.st->fail = fail_now; }      // NaN: breakdown
+    }
+    if (g.host_flag && threadIdx.x == 0)      // ONE aligned 8-byte store: the host never sees the fields of two gates mixed
+        *reinterpret_cast<volatile unsigned long long*>(g.host_flag) =
+            ((unsigned long long)(unsigned)g.seq << 32) | ((unsigned long long)(done_now ? 1u : 0u) << 31) | ((unsigned long long)((unsigned)fail_now & 7u) << 28) | (unsigned long long)((unsigned)iters & 0x0fffffffu);
+}
+
 // ------------------------------------------------------------------------------------------------
 // K1 lin_lm: per landmark — landmark-side linearisation of its LM edges.
 //   reads : slot planes zx zy w0 w1 + pose index (coalesced), pose state ps[i] = (x,y,c,s) (gather)
@@ -345,8 +366,13 @@ template <typename T, int G, int MODE, int LOW = 0>
 __global__ __launch_bounds__(kBlock) void k_schur_lm(Table<T> tb, const T* __restrict__ zc, T* __restrict__ lmrec,
                                                      const T* __restrict__ ninv, T* __restrict__ t, const CgState<T>* __restrict__ st,
                                                      T step, T* __restrict__ dl_out, T* __restrict__ norm_part,
-                                                     const float* __restrict__ zc32 = nullptr, float* __restrict__ t32 = nullptr) {
+                                                     const float* __restrict__ zc32 = nullptr, float* __restrict__ t32 = nullptr,
+                                                     const GateArgs<T> gate = GateArgs<T>{nullptr, nullptr, nullptr, 0, T(0), nullptr, 0}) {
     __shared__ T red[kWavesPerBlock];
+    // The iteration's stopping rule rides in workgroup 0 of its first product (gate.st set): one launch fewer per iteration.  The other
+    // workgroups do not wait for the verdict: a solve that has just converged runs this one pass for nothing (its output is scratch) and
+    // every later kernel of the iteration sees st->done.
+    if (MODE == 0 && gate.st != nullptr && blockIdx.x == 0) iter_gate_body<T>(gate, red);
     // the flag of a finished solve is requested here and tested after the loads that depend on the arguments alone (row bounds,
     // the vertex's inverse block) are on their way: tested first, it adds a scalar round trip in front of the first vector load
     const int done = MODE == 0 ? st->done : 0;

@@ -464,8 +464,14 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
                                                        int pose_first, int pose_last, T* __restrict__ out,
                                                        T* __restrict__ dot_part, const CgState<T>* __restrict__ st,
                                                        const T* __restrict__ rvec, T* __restrict__ rz_part,
-                                                       const float* __restrict__ zc32 = nullptr, const float* __restrict__ t32 = nullptr) {
+                                                       const float* __restrict__ zc32 = nullptr, const float* __restrict__ t32 = nullptr,
+                                                       const T* __restrict__ post_minv = nullptr, const T* __restrict__ post_r = nullptr,
+                                                       const T* __restrict__ post_omega = nullptr, T* __restrict__ zc_post = nullptr) {
     __shared__ T red[kWavesPerBlock];
+    // post_minv (the SECOND product inside a multigrid cycle, one shard, f32-copy operands): the level-0 post-smoothing
+    // zc_i += omega Minv_i (r_i - (S z)_i) in this kernel's epilogue instead of a launch of its own (k_smooth0<1>).  The pass gathers
+    // its operands from the f32 copies (zc32), so writing the f64 records it does not read is no race; the f32 copies are rewritten by
+    // k_cg_step before anything reads them again.
     const int done = st->done;      // requested now, tested after the first argument-only loads are in flight (see k_schur_lm)
     const int slice = (tb.xcd ? xcd_block() : (int)blockIdx.x) * kWavesPerBlock + (threadIdx.x >> 6);
     const bool live = slice < tb.n_slices;
@@ -492,6 +498,14 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
             for (int m = 0; m < 6; ++m) dpi[m] = dp[(size_t)i * 6 + m];
         }
         if (head && rvec) { rv0 = rvec[(size_t)i * 3]; rv1 = rvec[(size_t)i * 3 + 1]; rv2 = rvec[(size_t)i * 3 + 2]; }
+        T pm[6] = {0, 0, 0, 0, 0, 0}, pr0 = 0, pr1 = 0, pr2 = 0, pz0 = 0, pz1 = 0, pz2 = 0, pw = 0;      // post-smoothing operands: asked for before the rows are walked
+        if (LOW && post_minv && head) {
+#pragma unroll
+            for (int m = 0; m < 6; ++m) pm[m] = post_minv[(size_t)i * 6 + m];
+            pr0 = post_r[(size_t)i * 3]; pr1 = post_r[(size_t)i * 3 + 1]; pr2 = post_r[(size_t)i * 3 + 2];
+            const T* zr = zc_post + (size_t)i * kPoseRec;
+            pz0 = zr[0]; pz1 = zr[1]; pz2 = zr[2]; pw = *post_omega;
+        }
         T acc0 = 0, acc1 = 0, acc2 = 0;
         {
             const size_t S = tb.slots;
@@ -544,6 +558,12 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
             out[(size_t)i * 3] = o0; out[(size_t)i * 3 + 1] = o1; out[(size_t)i * 3 + 2] = o2;
             dot = o0 * v0 + o1 * v1 + o2 * v2;
             if (rvec) rz = rv0 * v0 + rv1 * v1 + rv2 * v2;
+            if (LOW && post_minv) {      // k_smooth0<1>: zc += omega Minv (r - S zc)
+                T z0, z1, z2;
+                sym3_mul<T>(pm, pr0 - o0, pr1 - o1, pr2 - o2, z0, z1, z2);
+                T* zr = zc_post + (size_t)i * kPoseRec;
+                zr[0] = pz0 + pw * z0; zr[1] = pz1 + pw * z1; zr[2] = pz2 + pw * z2;
+            }
         }
     }
     const T total = block_sum<T>(dot, red);

@@ -499,12 +499,14 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
         }
         if (head && rvec) { rv0 = rvec[(size_t)i * 3]; rv1 = rvec[(size_t)i * 3 + 1]; rv2 = rvec[(size_t)i * 3 + 2]; }
         T pm[6] = {0, 0, 0, 0, 0, 0}, pr0 = 0, pr1 = 0, pr2 = 0, pz0 = 0, pz1 = 0, pz2 = 0, pw = 0;      // post-smoothing operands: asked for before the rows are walked
-        if (LOW && post_minv && head) {
-#pragma unroll
-            for (int m = 0; m < 6; ++m) pm[m] = post_minv[(size_t)i * 6 + m];
+        if (LOW && post_r && head) {      // post_r alone (the FIRST product of a cycle): `out` receives the residual r - S z the restriction wants
             pr0 = post_r[(size_t)i * 3]; pr1 = post_r[(size_t)i * 3 + 1]; pr2 = post_r[(size_t)i * 3 + 2];
-            const T* zr = zc_post + (size_t)i * kPoseRec;
-            pz0 = zr[0]; pz1 = zr[1]; pz2 = zr[2]; pw = *post_omega;
+            if (post_minv) {
+#pragma unroll
+                for (int m = 0; m < 6; ++m) pm[m] = post_minv[(size_t)i * 6 + m];
+                const T* zr = zc_post + (size_t)i * kPoseRec;
+                pz0 = zr[0]; pz1 = zr[1]; pz2 = zr[2]; pw = *post_omega;
+            }
         }
         T acc0 = 0, acc1 = 0, acc2 = 0;
         {
@@ -555,7 +557,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_pose(Table<T> tb, Table<T> od,
                 sym3_mul<T>(dpi, v0, v1, v2, d0, d1, d2);
                 o0 += d0; o1 += d1; o2 += d2;
             }
-            out[(size_t)i * 3] = o0; out[(size_t)i * 3 + 1] = o1; out[(size_t)i * 3 + 2] = o2;
+            if (LOW && post_r && !post_minv) { out[(size_t)i * 3] = pr0 - o0; out[(size_t)i * 3 + 1] = pr1 - o1; out[(size_t)i * 3 + 2] = pr2 - o2; }
+            else { out[(size_t)i * 3] = o0; out[(size_t)i * 3 + 1] = o1; out[(size_t)i * 3 + 2] = o2; }
             dot = o0 * v0 + o1 * v1 + o2 * v2;
             if (rvec) rz = rv0 * v0 + rv1 * v1 + rv2 * v2;
             if (LOW && post_minv) {      // k_smooth0<1>: zc += omega Minv (r - S zc)

@@ -62,16 +62,11 @@ typedef struct tsgo_config {
     int32_t pcg_max_iters;   /* cap per Gauss-Newton iteration; default 20000 */
     int32_t lanes_per_pose;  /* 0 = auto; 1, 2, 4 or 8 lanes cooperate on one pose row */
     int32_t lanes_per_lm;    /* 0 = auto */
-    int32_t use_graphs;      /* 0: every PCG iteration is launched kernel by kernel.  1: replayed from a captured hipGraph (from the second
-                                tsgo_optimize on a structure on; the capture takes 15 ms at 100k poses).  2 (default): eager launches while the host
-                                thread stays well ahead of the device — on the GPU boxes' EPYC 9575F it enqueues an iteration in 90 us, the device
-                                runs it in 217, and eager is 1-3 % faster than the replay — and the replay as soon as it does not (two of a
-                                structure's first three solves whose bursts took more than 0.6 of the solve's own time per iteration to enqueue: no
-                                margin; later only outright starvation, 0.95 three times in a row).  Edge-sharded runs launch eagerly
-                                whatever this says (RCCL calls sit between the kernels).  Eager launches on one device are PACED: the first kernel of
-                                every iteration reports to pinned host memory, the host thread stays one iteration ahead and stops at the first
-                                report of convergence (no predicted burst, no drain at the end of a solve; it spins, yielding, on that word while
-                                the device works).  Same answers, bit for bit. */
+    int32_t use_graphs;      /* how the PCG iterations are launched.  0: kernel by kernel (eager).  1: replayed from a captured hipGraph (from the
+                                second tsgo_optimize on a structure on).  2 (default): eager while the host thread enqueues an iteration well
+                                within the time the device needs to run it, replay once it has been seen not to.  Eager launches on one device
+                                are paced by the first kernel of every iteration, which reports to pinned host memory; edge-sharded runs launch
+                                eagerly whatever this says (RCCL calls sit between the kernels).  Same answers, bit for bit. */
     int32_t rank, world;     /* edge sharding: this process owns shard `rank` of `world` (default 0, 1) */
     int32_t verbose;
     int32_t preconditioner;  /* 1 (default): smoothed-aggregation multigrid V-cycle on the reduced pose system; 0: block-Jacobi on its
@@ -97,25 +92,22 @@ typedef struct tsgo_config {
     int32_t reuse_structure; /* 1 (default): tsgo_set_graph with the SAME vertex ids/types, edge list and fixed list as the graph the
                                 handle already holds only refills estimates, measurements and weights (the reference re-creates
                                 everything per message, remote/app/ConnectionHandler.h:18-21); 0: always rebuild.  Same results. */
-    int32_t cycle_level0;    /* what the two level-0 products INSIDE the multigrid V-cycle read.  0 (default): the implicit Schur passes over
-                                the slot tables (f32 copy of the planes) — current with every linearisation; in an edge-sharded run each of
-                                them ends in an all-reduce.  1: the explicit level-0 matrix of the hierarchy (replicated on every shard, f32,
-                                as old as the hierarchy): no all-reduce inside the cycle, ~6 % more PCG iterations; what bench.py --gpus N
-                                (N > 1) runs.  The product PCG itself takes is always the implicit f64 one.  Same answers. */
-    int32_t cycle_storage;   /* 16 (default) or 32: how the copies of the hierarchy's matrices that the V-cycle reads (A_l, P_l, R_l, l >= 0) are
-                                stored — nine half floats with a common power-of-two exponent per 3x3 block (20 bytes), or nine f32 (36
-                                bytes).  A preconditioner tolerates the 11-bit blocks; PCG's own operator and every vector stay in
-                                `precision`.  Same answers, the same or one more PCG iteration per solve, fewer bytes per iteration.  A structure whose solves
-                                take more than 64 iterations (nearly singular systems: long odometry-only chains) is moved to 32 by the engine. */
+    int32_t cycle_level0;    /* what the two level-0 products INSIDE the multigrid V-cycle read.  0 (default): the implicit Schur passes over the
+                                slot tables (current with every linearisation; in an edge-sharded run each ends in an all-reduce).  1: the explicit
+                                level-0 matrix of the hierarchy (replicated on every shard, as old as the hierarchy): no all-reduce inside the
+                                cycle, a few per cent more PCG iterations; what bench.py --gpus N (N > 1) runs.  PCG's own product is always the
+                                implicit one in `precision`.  Same answers. */
+    int32_t cycle_storage;   /* 16 (default) or 32: the copies of the hierarchy's matrices that the V-cycle reads as nine half floats with a common
+                                power-of-two exponent per 3x3 block (20 bytes) or as nine f32 (36 bytes).  PCG's own operator and every vector stay
+                                in `precision`.  Same answers; a structure whose solves take more than 64 iterations (nearly singular systems) is
+                                moved to 32 by the engine (tsgo_stats.cycle_storage_now). */
     int32_t warm_requests;   /* 0 (default): every tsgo_set_graph starts the solver from nothing, so a handle's results are bit-identical to a
                                 fresh handle's.  1: the warm start's history (the pose deltas of the last Gauss-Newton iterations) survives
-                                tsgo_set_graph — a SLAM front-end resends the graph with the estimates it was returned, plus what it has seen
-                                since (python/slam_main.py:215-238), so the next request continues the damped iteration where the last one
-                                stopped.  Same structure: the history stays; a new (grown) structure: it is carried over by vertex id, poses the
-                                old graph did not hold start from zero.  A history that does not fit the new request (the first warm start
-                                leaves a larger residual than a cold start would) is dropped at that solve.  Same answer to pcg_rel_tol.
-                                ("warm-starting PCG across requests"; the reference re-creates everything per message,
-                                remote/app/ConnectionHandler.h:18-21.)  What graph_optimizer runs by default. */
+                                tsgo_set_graph — kept for the same structure, carried over by vertex id into a grown one, dropped at the first
+                                solve when it does not fit the new estimates — for a front-end that resends the graph with the estimates it was
+                                returned (python/slam_main.py:215-238; the reference re-creates everything per message,
+                                remote/app/ConnectionHandler.h:18-21).  Same answer to pcg_rel_tol.  What graph_optimizer runs, per connection
+                                (tsgo_reset_history). */
 } tsgo_config;
 
 enum { TSGO_STOP_CAP = 0, TSGO_STOP_WORSE = 1, TSGO_STOP_PLATEAU = 2, TSGO_STOP_CONVERGED = 3, TSGO_STOP_SOLVER = 4 };

@@ -165,6 +165,22 @@ def test_c3_three_iterations_followed_step_by_step_by_the_numpy_checker():
         o.close()
 
 
+def test_c5_one_iteration_followed_by_the_numpy_checker():
+    """The same at BASELINE config 5 (1 M poses / 10.1 M edges), one iteration: update and stop-rule arithmetic at the largest size
+    rest on the numpy checker too, not on the twin."""
+    o = HipOptimizer(pcg_rel_tol=1e-12)
+    try:
+        state = {}
+
+        def step_fn():
+            if "g" not in state:
+                state["g"] = synth.make_config("c5_1m"); o.set_graph(state["g"])
+            return o.solve_step()
+        _follow_step_by_step("c5_1m", 1, step_fn, o.vertices, lambda: o.optimize(1))
+    finally:
+        o.close()
+
+
 def test_c3_two_sharded_iterations_followed_step_by_step_by_the_numpy_checker():
     """The same through the edge-sharded device path: two in-process ranks (TSGO_TESTING library: the in-process all-reduce group),
     every call made by both ranks' threads; poses are replicated, each rank returns its own landmarks."""

@@ -27,7 +27,7 @@
 namespace tsgo {
 
 enum class VertexType : uint32_t { Se2 = 0, Point2 = 1 };
-enum class EdgeType : uint32_t { Se2 = 0, Se2Point2 = 1 };
+enum class EdgeType : uint32_t { Se2 = 0, Se2Point2 = 1, Se2VirtualPoint2 = 2 };      // 2: behind the C ABI only (include/tsgo.h), not in the reference's enum
 
 class Graph {
 public:
@@ -50,6 +50,12 @@ public:
     void AddEdgeSe2Point2(unsigned id_pose, unsigned id_landmark, double range, double bearing, double w0, double w1) {
         const double m[9] = {range, bearing, 0, 0, 0, 0, 0, 0, 0};
         push_edge(EdgeType::Se2Point2, id_pose, id_landmark, m, w0, w1, 0.0);
+    }
+    // Virtual landmark measurement (README.md:53; python/optimizer/edges2d.py:83-121): the same physical point seen from two poses as
+    // (range, bearing) each; information = diag(w0, w1).  No wire encoding exists for it.
+    void AddEdgeVirtualLandmark(unsigned id_pose_1, unsigned id_pose_2, double range1, double bearing1, double range2, double bearing2, double w0, double w1) {
+        const double m[9] = {range1, bearing1, range2, bearing2, 0, 0, 0, 0, 0};
+        push_edge(EdgeType::Se2VirtualPoint2, id_pose_1, id_pose_2, m, w0, w1, 0.0);
     }
     // generic form, same argument meaning as Functions::CreateEdge(type, id1, id2, meas, inf)
     // (DeserializeGraphFuncCpu.h:27-38): meas = 9 doubles row-major (ODOM) or (range, bearing, 0...) (LM)

@@ -85,3 +85,41 @@ def test_virtual_landmarks_through_the_sharded_device_path_and_in_f32():
     finally:
         o.close()
     np.testing.assert_allclose(r32["chi2"], rs["chi2"], rtol=2e-3)
+
+
+def test_python_graph_optimizer_takes_the_virtual_landmark_edge_class():
+    """toyslam_amd.optimizer.GraphOptimizer(graph).optimize(n) (the call shape of python/optimizer/graph_optimizer.py:11-20) on an
+    OptGraph that holds an EdgeVirtualLandmark2d, against the dense restatement of the same flattened graph."""
+    from toyslam_amd.graph import EdgeLandmark2d, EdgeOdometry2d, EdgeVirtualLandmark2d, GraphArrays, OptGraph, Vertex2d, VertexPose2d
+    from toyslam_amd.optimizer import GraphOptimizer
+    rng = np.random.default_rng(3)
+
+    def T(x, y, t):
+        c, s = np.cos(t), np.sin(t)
+        return np.array([[c, -s, x], [s, c, y], [0, 0, 1.0]])
+    og = OptGraph()
+    truth = [(0.0, 0.0, 0.0), (1.0, 0.1, 0.2), (2.0, 0.5, 0.5), (2.8, 1.2, 0.9)]
+    lms = [(1.5, 2.0), (3.0, -0.5), (2.5, 2.5)]
+    for i, (x, y, t) in enumerate(truth):
+        og.add_vertex(i, VertexPose2d(T(x + 0.1 * rng.normal(), y + 0.1 * rng.normal(), t + 0.05 * rng.normal())), fixed=(i == 0))
+    for j, (lx, ly) in enumerate(lms[:2]):
+        og.add_vertex(10 + j, Vertex2d([lx + 0.2 * rng.normal(), ly + 0.2 * rng.normal()]))
+
+    def obs(i, l):
+        x, y, t = truth[i]; dx, dy = l[0] - x, l[1] - y
+        return np.array([np.hypot(dx, dy), np.arctan2(dy, dx) - t])
+    for i in range(3):
+        og.add_edge(EdgeOdometry2d(i, i + 1, np.linalg.inv(T(*truth[i])) @ T(*truth[i + 1]), np.diag([4.0, 4.0, 65.0])))
+    for i in range(4):
+        for j in range(2):
+            og.add_edge(EdgeLandmark2d(i, 10 + j, obs(i, lms[j]), np.diag([44.0, 44.0])))
+    for a, b in ((0, 2), (1, 3), (0, 3)):                      # the third landmark has no vertex: three pose pairs that both saw it
+        og.add_edge(EdgeVirtualLandmark2d(a, b, obs(a, lms[2]), obs(b, lms[2]), np.diag([44.0, 44.0])))
+    arr = GraphArrays.from_optgraph(og)
+    ref = oracle.optimize(util.to_oracle(arr), 25, mode="cpp", solver="chol")
+    r = GraphOptimizer(og, pcg_rel_tol=1e-12).optimize(25)
+    assert (r["iters"], r["stop"]) == (ref["iters"], ref["stop"])
+    np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-9, atol=1e-12)
+    after = GraphArrays.from_optgraph(og)
+    assert util.max_vertex_diff(after.v_pos, ref["v_pos"], arr.v_type) < 1e-8
+    assert r["chi2"][-1] < 1e-3 * r["chi2"][0]                 # exact measurements: the estimate goes to the truth

@@ -102,3 +102,29 @@ def test_layout_accepts_virtual_landmarks_as_pose_pose_slots():
     bad = gv.copy(); bad.e_ids[np.where(bad.e_type == 2)[0][0], 1] = gv.v_id[gv.v_type == 1][0]      # a virtual measurement must join two poses
     cg = bad.c_struct()
     assert lib.tsgo_layout_probe(C.byref(cg), 0, 1, 0, 0, C.byref(a)) != 0 and b"must join two Se2 vertices" in lib.tsgo_last_error()
+
+
+def test_python_graph_model_carries_the_reference_sketchs_edge_class():
+    """toyslam_amd.graph.EdgeVirtualLandmark2d has the constructor of the class the reference keeps commented out
+    (python/optimizer/edges2d.py:83-89); GraphArrays flattens it to edge type 2; the wire encoder refuses it with the library's reason."""
+    from toyslam_amd import remote
+    from toyslam_amd.graph import EdgeLandmark2d, EdgeOdometry2d, EdgeVirtualLandmark2d, GraphArrays, OptGraph, Vertex2d, VertexPose2d
+
+    def pose(x, y, t):
+        c, s = np.cos(t), np.sin(t)
+        return VertexPose2d(np.array([[c, -s, x], [s, c, y], [0, 0, 1.0]]))
+    og = OptGraph()
+    og.add_vertex(0, pose(0, 0, 0.1), fixed=True); og.add_vertex(1, pose(1, 0.2, 0.3)); og.add_vertex(2, Vertex2d([2.0, 1.0]))
+    og.add_edge(EdgeOdometry2d(0, 1, np.array([[1, 0, 1.0], [0, 1, 0.1], [0, 0, 1.0]]), np.diag([4.0, 4.0, 65.0])))
+    og.add_edge(EdgeLandmark2d(0, 2, np.array([2.2, 0.4]), np.diag([44.0, 44.0])))
+    og.add_edge(EdgeVirtualLandmark2d(0, 1, np.array([2.2, 0.4]), np.array([1.3, 0.5]), np.diag([30.0, 20.0])))
+    e = og.get_edges()[-1]
+    assert e.get_type() == 2 and (e.get_id(0), e.get_id(1)) == (0, 1)
+    arr = GraphArrays.from_optgraph(og)
+    assert list(arr.e_type) == [0, 1, 2]
+    np.testing.assert_array_equal(arr.e_meas[2], [2.2, 0.4, 1.3, 0.5, 0, 0, 0, 0, 0])
+    np.testing.assert_array_equal(arr.e_inf[2], [30.0, 20.0, 0.0])
+    r = oracle.optimize(util.to_oracle(arr), 5, mode="cpp", solver="qr")          # the dense restatement takes the flattened graph
+    assert r["iters"] >= 1 and np.isfinite(r["chi2"]).all()
+    with pytest.raises(RuntimeError, match="ODOM .0. and LM .1. edges only"):
+        remote.graph_to_bytes(og)

@@ -1,7 +1,7 @@
 """The OptGraph model on the Python host side.
 
 Two views of the same thing:
-  * OptGraph / VertexPose2d / Vertex2d / EdgeOdometry2d / EdgeLandmark2d — same names, constructor
+  * OptGraph / VertexPose2d / Vertex2d / EdgeOdometry2d / EdgeLandmark2d (+ EdgeVirtualLandmark2d, the reference's commented-out sketch) — same names, constructor
     arguments and get_type()/get_dims() values as the reference's python/optimizer/opt_graph.py:1-31,
     vertices.py:18-46 and edges2d.py:14-81, so code written against those keeps working;
   * GraphArrays — the structure-of-arrays form the C ABI takes (include/tsgo.h, struct tsgo_graph).
@@ -59,6 +59,27 @@ class EdgeLandmark2d(_Edge):
 
     def get_type(self):
         return 1
+
+
+class EdgeVirtualLandmark2d:
+    """Virtual landmark measurement (edge type 2, include/tsgo.h): two poses that observed the same physical point, no landmark vertex.
+    Constructor arguments as in the sketch the reference keeps commented out (python/optimizer/edges2d.py:83-89):
+    (pos_id_1, pos_id_2, lm_meas_1, lm_meas_2, information) with lm_meas_k = (range, bearing) as seen from pose k and a 2 x 2
+    information matrix (its diagonal is used, as for every other edge).  Behind the C ABI only: remote.graph_to_bytes refuses it."""
+
+    def __init__(self, pos_id_1, pos_id_2, lm_meas_1, lm_meas_2, information):
+        self.id_1, self.id_2 = pos_id_1, pos_id_2
+        self.pos_id_1, self.pos_id_2 = pos_id_1, pos_id_2
+        self.lm_meas_1 = np.asarray(lm_meas_1, dtype=np.float64)
+        self.lm_meas_2 = np.asarray(lm_meas_2, dtype=np.float64)
+        self.measurement = np.concatenate([self.lm_meas_1[:2], self.lm_meas_2[:2]])
+        self.information = np.asarray(information, dtype=np.float64)
+
+    def get_type(self):
+        return 2
+
+    def get_id(self, index):
+        return self.id_1 if index == 0 else self.id_2
 
 
 class OptGraph:
@@ -202,6 +223,8 @@ class GraphArrays:
             meas = np.asarray(e.measurement, dtype=np.float64); inf = np.asarray(e.information, dtype=np.float64)
             if e.get_type() == 0:
                 m[:] = meas.reshape(-1); w[:] = np.diag(inf)
+            elif e.get_type() == 2:
+                m[:4] = meas.reshape(-1)[:4]; w[:2] = np.diag(inf)[:2]
             else:
                 m[:2] = meas.reshape(-1)[:2]; w[:2] = np.diag(inf)[:2]
             etype.append(e.get_type()); eids.append([e.id_1, e.id_2]); emeas.append(m); einf.append(w)

@@ -23,6 +23,8 @@ def graph_to_bytes(graph):
     lib = _lib.host_lib()
     g = _arrays(graph).c_struct()
     n = lib.tsgo_wire_encode_request(C.byref(g), None, 0)
+    if n < 0:      # e.g. an edge type the wire format cannot carry (virtual landmark measurements: behind the C ABI only)
+        raise RuntimeError("graph_to_bytes: " + lib.tsgo_last_error().decode())
     buf = (C.c_uint8 * n)()
     lib.tsgo_wire_encode_request(C.byref(g), buf, n)
     return bytes(buf)

@@ -851,3 +851,31 @@ def test_randomised_graphs_against_cpu_eigen():
         np.testing.assert_allclose(r["chi2"], ref["chi2"], rtol=1e-8)
         assert util.max_vertex_diff(v, ref["v_pos"], g.v_type) < 1e-7, (trial, n, k)
     assert worst <= 1e-7
+
+
+def test_reset_history_makes_a_pooled_handle_start_like_a_fresh_one():
+    """tsgo_reset_history: a handle with tsgo_config.warm_requests that changes hands forgets the solver history it holds —
+    the next request, same structure or a new one, runs bit for bit like on a fresh handle."""
+    from toyslam_amd.graph import GraphArrays
+    g = synth.make(2500, 8, seed=31)
+    o = HipOptimizer(pcg_rel_tol=1e-10, warm_requests=True)
+    fresh = HipOptimizer(pcg_rel_tol=1e-10, warm_requests=True)
+    try:
+        o.set_graph(g); r0 = o.optimize(6); v0 = o.vertices()
+        g1 = GraphArrays(g.v_id, g.v_type, v0, g.e_type, g.e_ids, g.e_meas, g.e_inf, g.fixed)
+        o.set_graph(g1); r1 = o.optimize(6)
+        assert r0["history_carried"] == 0 and r1["history_carried"] in (1, 2)
+        o.reset_history()
+        o.set_graph(g1); r2 = o.optimize(6); v2 = o.vertices()          # same structure: refilled, history forgotten
+        fresh.set_graph(g1); rf = fresh.optimize(6); vf = fresh.vertices()
+        assert r2["history_carried"] == 0 and r2["structure_reused"]
+        np.testing.assert_array_equal(r2["chi2"], rf["chi2"]); np.testing.assert_array_equal(r2["cg_iters"], rf["cg_iters"]); np.testing.assert_array_equal(v2, vf)
+        assert r1["cg_iters"].sum() <= r2["cg_iters"].sum()                  # what the history had bought
+        g2 = synth.make(2600, 8, seed=31)                                     # a new structure after a reset: nothing carried over either
+        o.set_graph(g1); o.optimize(3); o.reset_history()
+        o.set_graph(g2); r3 = o.optimize(4)
+        fresh.set_graph(g2); rf3 = fresh.optimize(4)
+        assert r3["history_carried"] == 0
+        np.testing.assert_array_equal(r3["chi2"], rf3["chi2"]); np.testing.assert_array_equal(r3["cg_iters"], rf3["cg_iters"])
+    finally:
+        o.close(); fresh.close()

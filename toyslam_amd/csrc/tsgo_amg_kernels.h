@@ -958,6 +958,20 @@ __global__ __launch_bounds__(kBlock) void k_norm2(int n3, const T* __restrict__ 
 // and sets `done`: a converged solve does not run one more V-cycle and product just to learn that it was finished (the rule on
 // r^T M^-1 r could only be tested after applying M^-1).  (The sum inside this kernel by the last-arriving workgroup was measured:
 // its agent-scope release drains the 24 MB this kernel has just written, 12 -> 30 us; profiles/r03b_*.)
+// Large graphs: every workgroup of k_cg_step sums ALL the partials of the two dot products (3 900 each at a million poses: 62 KB per
+// workgroup, 244 MB over the launch — as much as the vectors it updates).  Above kFoldAbove partials they are first folded to kFoldOut
+// per sum, in fixed order (chunk by chunk), by this kernel: out[w * kFoldOut + b] = sum of chunk b of array w.
+constexpr int kFoldAbove = 1024, kFoldOut = 64;
+template <typename T>
+__global__ __launch_bounds__(kBlock) void k_fold_partials(int n, const T* __restrict__ a0, const T* __restrict__ a1, T* __restrict__ out) {
+    __shared__ T red[kWavesPerBlock];
+    const T* a = blockIdx.y == 0 ? a0 : a1;
+    const int chunk = (n + kFoldOut - 1) / kFoldOut;
+    const int b0 = min(n, (int)blockIdx.x * chunk), b1 = min(n, b0 + chunk);
+    const T total = block_sum_array<T>(a + b0, b1 - b0, red);
+    if (threadIdx.x == 0) out[blockIdx.y * kFoldOut + blockIdx.x] = total;
+}
+
 template <typename T>
 __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__ sz, const T* __restrict__ dot_part,
                                                     const T* __restrict__ rz_part, int n_part, const CgState<T>* __restrict__ st_in,
@@ -987,20 +1001,42 @@ __global__ __launch_bounds__(kBlock) void k_cg_step(int P, const T* __restrict__
     if (s.iters == 0) { beta = 0; alpha = gamma / delta; }
     else { beta = gamma / s.gamma_old; alpha = gamma / (delta - beta * gamma / s.alpha_old); }
     if (!(alpha > 0) || !(alpha < T(1e300))) { n.done = 1; n.fail = 1; if (writer) *st_out = n; return; }
-    const int i = blockIdx.x * kBlock + threadIdx.x;
+    // The vector updates element by element (lane = element: every load and store of a wavefront is one contiguous 512 bytes; lane = pose
+    // made them 24-byte-strided triples), the residual and the diagonal inverses handed to the per-pose part through LDS.
+    __shared__ T s_r[3 * kBlock];
+    __shared__ T s_m[6 * kBlock];
+    const int i0 = blockIdx.x * kBlock;
+    const int n_here = min(kBlock, P - i0);
+    {
+        const size_t e0 = (size_t)i0 * 3;
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int le = (int)threadIdx.x + m * kBlock;
+            if (le < 3 * n_here) {
+                const size_t j = e0 + le;
+                const int ip = le / 3, k = le - 3 * ip;
+                const T pk = zc[(size_t)(i0 + ip) * kPoseRec + k] + beta * p[j];
+                const T qk = sz[j] + beta * q[j];
+                p[j] = pk; q[j] = qk; x[j] += alpha * pk;
+                const T rk = r[j] - alpha * qk;
+                r[j] = rk; s_r[le] = rk;
+            }
+        }
+        const T* mi = minv + (size_t)i0 * 6;
+#pragma unroll
+        for (int m = 0; m < 6; ++m) {
+            const int le = (int)threadIdx.x + m * kBlock;
+            if (le < 6 * n_here) s_m[le] = mi[le];
+        }
+    }
+    __syncthreads();
+    const int i = i0 + threadIdx.x;
     T g = 0;
     if (i < P) {
-        T rr[3];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-            const size_t j = (size_t)i * 3 + k;
-            const T pk = zc[(size_t)i * kPoseRec + k] + beta * p[j];
-            const T qk = sz[j] + beta * q[j];
-            p[j] = pk; q[j] = qk; x[j] += alpha * pk; rr[k] = r[j] - alpha * qk; r[j] = rr[k];
-        }
+        const T rr[3] = {s_r[3 * threadIdx.x], s_r[3 * threadIdx.x + 1], s_r[3 * threadIdx.x + 2]};
         // level-0 pre-smoothing of the NEXT V-cycle (zero initial guess): zc = Minv r
         T z0, z1, z2;
-        sym3_mul<T>(minv + (size_t)i * 6, rr[0], rr[1], rr[2], z0, z1, z2);
+        sym3_mul<T>(s_m + 6 * threadIdx.x, rr[0], rr[1], rr[2], z0, z1, z2);
         const T w = *omega_ptr;
         T* zr = zc + (size_t)i * kPoseRec;
         zr[0] = w * z0; zr[1] = w * z1; zr[2] = w * z2;

@@ -270,7 +270,7 @@ template <typename T> struct Engine : IEngine {
     int *last_ptr = nullptr, *last_col = nullptr; int nb_last = 0, nnz_last = 0;
     using H = HT<T>;
     H* A_last = nullptr;
-    T *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr;
+    T *inv_last = nullptr, *r_last = nullptr, *z_last = nullptr, *rzpart = nullptr, *fold_part = nullptr;
     double ms_amg_symbolic = 0;
     T *omega_dev = nullptr, *one_dev = nullptr, *gscale_dev = nullptr, *pw_a = nullptr, *pw_b = nullptr, *rho_part = nullptr;
     T* h_rho = nullptr;                 // pinned

@@ -365,6 +365,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    allreduce_us = None
+    if shard or (ARGS.force_collective and world == 1):
+        # what each of the solver's collectives costs on THIS fabric (every rank calls alike): after a sharded product, after a linearisation,
+        # after the level-0 blocks of a hierarchy build (that one is f32 in the solver; timed here in the handle's precision at the same BYTES)
+        word = 8 if ARGS.precision == 64 else 4
+        sizes = {"product_3P": 3 * g.n_poses + 400, "linearisation_18P": 18 * g.n_poses + 400, "level0_blocks_60MB": int(60e6) // word}
+        with watch.phase("timing the all-reduces of the three buffer sizes", ARGS.phase_timeout):
+            allreduce_us = {k: {"bytes": n * word, "us": opt.comm_time_allreduce(n, reps=(50 if n * word < 8e6 else 10))} for k, n in sizes.items()}
     if shard:                                         # the first iteration carries every kind of collective the run will issue
         with watch.phase("first sharded Gauss-Newton iteration (pose-partial, product and level-0 all-reduces)", ARGS.phase_timeout):
             opt.optimize(1)
@@ -504,6 +512,7 @@ def main():
                                        ("single GPU, collective code path forced (one-rank RCCL communicator)" if ARGS.force_collective else "single GPU")),
                        "hipgraph": graph_replay, "launch_mode": "tsgo_config.use_graphs = %d (%s)" % (0 if ARGS.no_graphs else (1 if ARGS.graphs else 2), "hipGraph replay" if graph_replay else "eager launches")},
             "rccl_ranks": rccl_ranks,
+            "allreduce_us": allreduce_us,
             "multi_gpu_design": (("A: landmark-range edge shards, replicated multigrid hierarchy and PCG vectors (DESIGN.md section 5); value = this one graph's edges x K / max-over-ranks time" if shard else
                                   "request-parallel: one graph per GPU, no collective") if world > 1 else None),
             "request_parallel": req_par,

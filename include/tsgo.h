@@ -184,6 +184,11 @@ int tsgo_comm_init(tsgo_optimizer* opt, const uint8_t id[128]);
  * communicator's own rank count (ncclCommCount) in *ranks_out (1 without a communicator).  The first collective is where a
  * missing peer shows — as a hang: callers run it under a watchdog (bench.py). */
 int tsgo_comm_selftest(tsgo_optimizer* opt, int32_t* ranks_out);
+/* Timing probe used by bench.py on more than one GPU: `reps` back-to-back all-reduces (sum) of n_elements numbers of the handle's
+ * precision on the handle's communicator and stream — the call the solver makes after a sharded product (3 P + partials), after a
+ * linearisation (18 P + partials) and after the level-0 blocks of a hierarchy build; *us_per_call = hipEvent time / reps.  Every rank
+ * of the communicator must call it with the same arguments.  0 microseconds without a communicator. */
+int tsgo_comm_time_allreduce(tsgo_optimizer* opt, int64_t n_elements, int32_t reps, double* us_per_call);
 /* Timing probe used by bench.py: average device time (hipEvent, microseconds) of `reps` back-to-back
  * launches of one kernel on the handle's stream, and the algorithmic bytes one launch moves.
  * which: 0 schur_lm, 1 schur_pose, 2 cg_update, 3 lin_lm, 4 lin_pose, 5 one whole PCG iteration

@@ -98,4 +98,6 @@ def test_the_bench_line_keeps_its_contract_on_one_gpu():
     assert rc == 0, err[-3000:]
     d2 = json.loads([l for l in out.splitlines() if l.strip()][-1])
     assert d2["rccl_ranks"] == 1 and "collective code path forced" in d2["config"]["parallelism"]
+    assert d["allreduce_us"] is None and set(d2["allreduce_us"]) == {"product_3P", "linearisation_18P", "level0_blocks_60MB"}      # tsgo_comm_time_allreduce: RCCL calls of the solver's three buffer sizes
+    assert all(v["us"] > 0 and v["bytes"] > 0 for v in d2["allreduce_us"].values()), d2["allreduce_us"]
     assert abs(d2["chi2_first_last"][0] - d["chi2_first_last"][0]) <= 1e-9 * d["chi2_first_last"][0]

@@ -150,6 +150,7 @@ struct IEngine {
     virtual int cycle_probe(int reps, tsgo_cycle_level* out, int cap) = 0;
     virtual int profile_iteration(int reps, tsgo_prof_entry* out, int cap) = 0;
     virtual int comm_selftest(int* ranks_out) = 0;
+    virtual int comm_time_allreduce(int64_t n, int reps, double* us) = 0;
     virtual void reset_history() = 0;
     ncclComm_t comm = nullptr;
     tsgo_local_group* lgroup = nullptr;      // in-process stand-in for the communicator (tests on a one-GPU box; always null outside TSGO_TESTING builds)
@@ -510,6 +511,10 @@ int tsgo_comm_selftest(tsgo_optimizer* o, int32_t* ranks_out) {
     const int rc = o->eng->comm_selftest(&n);
     if (ranks_out) *ranks_out = n;
     return rc;
+}
+int tsgo_comm_time_allreduce(tsgo_optimizer* o, int64_t n_elements, int32_t reps, double* us_per_call) {
+    if (!o || !us_per_call || n_elements <= 0 || reps <= 0) return tsgo::set_error(-1, "tsgo_comm_time_allreduce: bad argument");
+    return o->eng->comm_time_allreduce(n_elements, reps, us_per_call);
 }
 int tsgo_comm_unique_id(uint8_t id_out[128]) {
     static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId size");

@@ -145,6 +145,12 @@ class HipOptimizer:
         _lib.check(self.lib, self.lib.tsgo_comm_selftest(self.h, C.byref(n)), "tsgo_comm_selftest")
         return n.value
 
+    def comm_time_allreduce(self, n_elements, reps=50):
+        """Microseconds per all-reduce of n_elements numbers of the handle's precision on its communicator (every rank calls it alike)."""
+        us = C.c_double()
+        _lib.check(self.lib, self.lib.tsgo_comm_time_allreduce(self.h, int(n_elements), int(reps), C.byref(us)), "tsgo_comm_time_allreduce")
+        return us.value
+
 
 def local_group(world):
     """An in-process all-reduce group for `world` HipOptimizer(testing=True) handles (tests of the sharded path on a one-GPU box)."""

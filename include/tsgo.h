@@ -141,6 +141,10 @@ typedef struct tsgo_stats {
 /* Fills cfg with defaults. */
 void tsgo_default_config(tsgo_config* cfg);
 
+/* GPUs visible to this process (hipGetDeviceCount; 0 when none or on error): tsgo_config.device picks one of them per handle.  The
+ * server's DEVICE=all spreads its engine pool over them (host/server.cpp); the reference has one device (GraphManager.h:73-122). */
+int tsgo_device_count(void);
+
 /* Replaces CreateOptimizer/CreateSolver/CreateGraph (remote/app/GraphManager.h:73-122): one handle
  * holds the device buffers and is reusable across requests. */
 int tsgo_create(const tsgo_config* cfg, tsgo_optimizer** out);

@@ -269,3 +269,53 @@ def test_trailing_arguments_select_the_python_rules_and_the_analytic_odometry_ja
     out = proc.stdout.read()
     assert "lr 0.5" in out and "analytic" in out
     assert util.max_vertex_diff(got, want, g.v_type) < 1e-4               # the reply is f32 on the wire
+
+
+def test_the_engine_pool_spreads_connections_over_the_listed_gpus():
+    """DEVICE takes a list (or "all"): ENGINES handles on EACH listed GPU, a request goes to its connection's own last handle when that is
+    idle, else to the listed GPU with the fewest requests in flight — one graph per GPU, no collective (how the server uses a node).  A
+    one-GPU box rehearses it with the same GPU listed twice ("0,0", one handle each): two clients at once land on different pools, each
+    connection then stays on its pool (same structure refilled, history carried), answers equal to the twin's."""
+    import threading
+    from toyslam_amd import synth
+    graphs = [synth.make(2500 + 500 * k, 6, loop_closures=4, seed=60 + k) for k in range(2)]
+    refs = [oracle.sparse_optimize(util.to_oracle(g.rounded_to_wire()), 6, pcg_tol=1e-12, precond="amg") for g in graphs]
+    port, proc = _start(6, "64", "1e-10", "0,0", "1")
+    outs = [None, None]
+    errs = []
+    start = threading.Barrier(2)
+
+    def client(k):
+        try:
+            c = remote.GraphClient("127.0.0.1", port)
+            c.connect()
+            start.wait(timeout=30)
+            for _ in range(3):
+                outs[k] = c.optimize(graphs[k])
+            c.close()
+        except Exception as e:                      # noqa: BLE001 - reported below
+            errs.append((k, repr(e)))
+
+    try:
+        th = [threading.Thread(target=client, args=(k,)) for k in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=120)
+        assert not errs, errs
+        assert proc.poll() is None
+    finally:
+        _stop(proc)
+    out = proc.stdout.read()
+    assert "engine pool over 2 GPUs (0,0), 1 handle(s) each" in out
+    lines = [l for l in out.splitlines() if l.startswith(" [hip]") and "iterations=6" in l]
+    assert len(lines) == 6, out[-3000:]
+    pools = [l.rsplit("pool=", 1)[1].strip() for l in lines]
+    assert sorted(set(pools)) == ["0", "1"] and pools.count("0") == 3 and pools.count("1") == 3, pools      # both pools used, each connection kept its own
+    assert sum("structure=reused" in l for l in lines) == 4 and sum("history=1" in l for l in lines) == 4, lines
+    for k in range(2):
+        assert util.max_vertex_diff(outs[k].v_pos, refs[k]["v_pos"], graphs[k].v_type) < 2e-4    # f32 on the wire
+    # a GPU that does not exist is refused at start-up, like a pipeline the reference cannot create
+    exe = build.SERVER
+    r = subprocess.run([exe, "127.0.0.1", str(_free_port()), "1", "gpu", "cuda", "64", "1e-10", "0,99"], capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "ConnectionManager error" in r.stderr

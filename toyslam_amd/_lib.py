@@ -55,7 +55,7 @@ class tsgo_amg_info(C.Structure):
 HOST_SYMBOLS = ["tsgo_default_config", "tsgo_last_error", "tsgo_wire_decode", "tsgo_wire_new", "tsgo_wire_decode_into", "tsgo_wire_view", "tsgo_wire_free",
                 "tsgo_wire_encode_response", "tsgo_wire_encode_request", "tsgo_synth_create", "tsgo_synth_view",
                 "tsgo_synth_truth", "tsgo_synth_free", "tsgo_layout_probe", "tsgo_amg_probe", "tsgo_amg_probe_shard"]
-DEVICE_SYMBOLS = ["tsgo_create", "tsgo_destroy", "tsgo_set_graph", "tsgo_reset_history", "tsgo_optimize", "tsgo_get_vertices",
+DEVICE_SYMBOLS = ["tsgo_device_count", "tsgo_create", "tsgo_destroy", "tsgo_set_graph", "tsgo_reset_history", "tsgo_optimize", "tsgo_get_vertices",
                   "tsgo_linearize", "tsgo_solve_step", "tsgo_comm_unique_id", "tsgo_comm_init", "tsgo_comm_selftest", "tsgo_comm_time_allreduce", "tsgo_time_kernel", "tsgo_cycle_probe", "tsgo_profile_iteration"]
 TESTING_SYMBOLS = ["tsgo_local_group_create", "tsgo_local_group_destroy", "tsgo_comm_init_local"]      # include/tsgo_testing.h: libtsgo_hip_testing.so only
 
@@ -95,6 +95,7 @@ def _declare_device(L):
     L.tsgo_comm_unique_id.argtypes = [vp]
     L.tsgo_comm_init.argtypes = [vp, vp]
     L.tsgo_comm_selftest.argtypes = [vp, C.POINTER(C.c_int32)]
+    L.tsgo_device_count.argtypes = []
     L.tsgo_comm_time_allreduce.argtypes = [vp, C.c_int64, C.c_int32, C.POINTER(C.c_double)]
     L.tsgo_time_kernel.argtypes = [vp, C.c_int32, C.c_int32, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     L.tsgo_cycle_probe.argtypes = [vp, C.c_int32, C.POINTER(tsgo_cycle_level), C.c_int32]

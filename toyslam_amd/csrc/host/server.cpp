@@ -2,6 +2,9 @@
 //
 //   graph_optimizer [HOST=127.0.0.1] [PORT=8888] [ITERATIONS=10] [PIPELINE=cpu] [SOLVER=eigen]
 //                   [PRECISION=64] [PCG_TOL=1e-10] [DEVICE=0] [ENGINES=2] [RULES=cpp] [ODOM_JACOBIAN=constant] [WARM_REQUESTS=1]
+//   DEVICE: one GPU ("0"), a list ("0,1,2,3") or "all": the engine pool then spans the listed GPUs, ENGINES handles on EACH; a request
+//   goes to its connection's last handle when that is idle (it holds the connection's structure and solver history), else to the listed
+//   GPU with the fewest requests in flight.  One graph per GPU, no collective: how this server uses a node.
 //   RULES "python" or "python:LR": the loop of the reference's in-process Python optimizer instead (lambda * I damping, step LR,
 //   default 0.2 as slam_main.py passes); ODOM_JACOBIAN "analytic": the extension of tsgo_config.odom_jacobian.  Both default to
 //   what the reference's C++ server does.  WARM_REQUESTS 1: tsgo_config.warm_requests (a connection's next request starts its PCG
@@ -81,7 +84,11 @@ bool write_all(int fd, const void* buf, size_t n) {
 
 struct Server {
     tsgo_config cfg;
-    int max_engines = 2;
+    int max_engines = 2;                    // per listed device
+    std::vector<int> devices{0};            // the pool's GPUs (DEVICE argument); the same GPU may be listed twice (two pools on it)
+    struct Slot { int created = 0, busy = 0; };
+    std::vector<Slot> slots;                // per entry of `devices`
+    std::vector<std::pair<tsgo_optimizer*, int>> slot_of;      // handle -> entry of `devices` (pool_mutex)
     std::vector<tsgo_optimizer*> idle;      // engine handles not in use
     std::vector<std::pair<tsgo_optimizer*, uint64_t>> last_user;   // per handle: the session it served last (pool_mutex)
     uint64_t next_session = 1;
@@ -102,29 +109,44 @@ struct Server {
     // An engine handle for one request: the one this connection used last when it is idle (it still holds that
     // connection's graph structure: a repeated structure only refills values, tsgo_config::reuse_structure), else an
     // idle one, else a new one while fewer than max_engines exist, else wait.
-    tsgo_optimizer* acquire(tsgo_optimizer* preferred = nullptr) {
+    int slot_index(tsgo_optimizer* o) const { for (auto& e : slot_of) if (e.first == o) return e.second; return 0; }
+    // on_slot >= 0: a handle of that entry of `devices` only (start-up: every listed GPU is warmed once)
+    tsgo_optimizer* acquire(tsgo_optimizer* preferred = nullptr, int on_slot = -1) {
         std::unique_lock<std::mutex> lock(pool_mutex);
+        if (slots.size() != devices.size()) slots.resize(devices.size());
         for (;;) {
             if (preferred) {
                 auto it = std::find(idle.begin(), idle.end(), preferred);
-                if (it != idle.end()) { idle.erase(it); return preferred; }
+                if (it != idle.end()) { idle.erase(it); ++slots[slot_index(preferred)].busy; return preferred; }
             }
-            // an engine nobody's connection prefers would be ideal; without that bookkeeping take the least recently released one,
-            // which leaves the most recently used handles (and their cached structures) to the connections that used them
-            if (!idle.empty()) { tsgo_optimizer* o = idle.front(); idle.erase(idle.begin()); return o; }
-            if (created < max_engines) {
+            // the listed GPU with the fewest requests in flight that can take one more (an idle handle, or room for a new one); among its
+            // idle handles the least recently released, which leaves the recently used ones (and their cached structures) to the
+            // connections that used them
+            int best = -1;
+            for (int d = 0; d < (int)slots.size(); ++d) {
+                if (on_slot >= 0 && d != on_slot) continue;
+                const bool has_idle = std::any_of(idle.begin(), idle.end(), [&](tsgo_optimizer* o) { return slot_index(o) == d; });
+                if (!has_idle && slots[d].created >= max_engines) continue;
+                if (best < 0 || slots[d].busy < slots[best].busy) best = d;
+            }
+            if (best >= 0) {
+                for (auto it = idle.begin(); it != idle.end(); ++it)
+                    if (slot_index(*it) == best) { tsgo_optimizer* o = *it; idle.erase(it); ++slots[best].busy; return o; }
+                tsgo_config c = cfg; c.device = devices[best];
                 tsgo_optimizer* o = nullptr;
-                if (tsgo_create(&cfg, &o)) return nullptr;
-                ++created;
+                if (tsgo_create(&c, &o)) return nullptr;
+                ++created; ++slots[best].created; ++slots[best].busy;
+                slot_of.emplace_back(o, best);
                 return o;
             }
             pool_cv.wait(lock);
         }
     }
     void release(tsgo_optimizer* o) {
-        { std::lock_guard<std::mutex> lock(pool_mutex); idle.push_back(o); }
-        pool_cv.notify_one();
+        { std::lock_guard<std::mutex> lock(pool_mutex); idle.push_back(o); --slots[slot_index(o)].busy; }
+        pool_cv.notify_all();
     }
+    int slot_index_locked(tsgo_optimizer* o) { std::lock_guard<std::mutex> lock(pool_mutex); return slot_index(o); }
     uint64_t new_session() { std::lock_guard<std::mutex> lock(pool_mutex); return next_session++; }
     // The handle now serves `session`: true when the last request it served was another session's (or nobody's).  The solver
     // history a handle keeps under WARM_REQUESTS belongs to the connection whose requests built it.
@@ -188,7 +210,7 @@ struct Server {
                 std::cout << "Summary() error = " << st.chi2_last << std::endl;                        // :182
                 std::cout << " [hip] iterations=" << st.iterations_run << " pcg_iters=" << st.pcg_iters_total
                           << (st.structure_reused ? " structure=reused refill=" : " structure=built setup=") << st.ms_setup << "ms linearize=" << st.ms_linearize << "ms solve=" << st.ms_solve
-                          << "ms update=" << st.ms_update << "ms history=" << st.history_carried << std::endl;
+                          << "ms update=" << st.ms_update << "ms history=" << st.history_carried << " gpu=" << devices[slot_index_locked(opt)] << " pool=" << slot_index_locked(opt) << std::endl;
             }
         }
         if (ok) {
@@ -257,7 +279,20 @@ int main(int argc, char* argv[]) {
         const std::string solverS = argc < 6 ? "eigen" : argv[5];
         const int precision = argc < 7 ? 64 : std::stoi(argv[6]);
         const double tol = argc < 8 ? 1e-10 : std::stod(argv[7]);
-        const int device = argc < 9 ? 0 : std::stoi(argv[8]);
+        const std::string deviceS = argc < 9 ? "0" : argv[8];
+        std::vector<int> devices;
+        if (deviceS == "all") {
+            const int n = tsgo_device_count();
+            if (n <= 0) { std::cerr << "ConnectionManager error: DEVICE=all, but no GPU is visible" << std::endl; return 1; }
+            for (int d = 0; d < n; ++d) devices.push_back(d);
+        } else {
+            for (size_t b = 0; b <= deviceS.size();) {
+                const size_t e = std::min(deviceS.find(',', b), deviceS.size());
+                devices.push_back(std::stoi(deviceS.substr(b, e - b)));
+                b = e + 1;
+            }
+        }
+        const int device = devices[0];
         const int engines = argc < 10 ? 2 : std::max(1, std::stoi(argv[9]));
         const std::string rulesS = argc < 11 ? "cpp" : argv[10];
         const std::string odomS = argc < 12 ? "constant" : argv[11];
@@ -279,10 +314,15 @@ int main(int argc, char* argv[]) {
         }
         if (odomS == "analytic") { cfg.odom_jacobian = 1; std::cout << "ODOM Jacobians: analytic (extension)\n"; }
         cfg.warm_requests = warm_requests ? 1 : 0;      // a connection's next request continues from the last one's solver history (tsgo.h)
-        Server srv; srv.iterations = iters; srv.cfg = cfg; srv.max_engines = engines;
+        Server srv; srv.iterations = iters; srv.cfg = cfg; srv.max_engines = engines; srv.devices = devices;
+        if (devices.size() > 1) {
+            std::cout << "engine pool over " << devices.size() << " GPUs (";
+            for (size_t k = 0; k < devices.size(); ++k) std::cout << (k ? "," : "") << devices[k];
+            std::cout << "), " << engines << " handle(s) each\n";
+        }
         if (const char* e = getenv("TSGO_MAX_MESSAGE_MB")) srv.max_message_bytes = (size_t)std::max(1, atoi(e)) << 20;
-        {   // fail at start-up, like the reference, when the pipeline cannot be created at all
-            tsgo_optimizer* first = srv.acquire();
+        for (int slot = 0; slot < (int)devices.size(); ++slot) {   // fail at start-up, like the reference, when the pipeline cannot be created at all (on any listed GPU)
+            tsgo_optimizer* first = srv.acquire(nullptr, slot);
             if (!first) { std::cerr << "ConnectionManager error: " << tsgo_last_error() << std::endl; return 1; }
             {   // one small solve before the first client: loads every kernel's code object and sizes the runtime's pools,
                 // so that the first request does not pay for it (the code objects are per process, not per engine)

@@ -512,6 +512,10 @@ int tsgo_comm_selftest(tsgo_optimizer* o, int32_t* ranks_out) {
     if (ranks_out) *ranks_out = n;
     return rc;
 }
+int tsgo_device_count(void) {
+    int n = 0;
+    return hipGetDeviceCount(&n) == hipSuccess ? n : 0;
+}
 int tsgo_comm_time_allreduce(tsgo_optimizer* o, int64_t n_elements, int32_t reps, double* us_per_call) {
     if (!o || !us_per_call || n_elements <= 0 || reps <= 0) return tsgo::set_error(-1, "tsgo_comm_time_allreduce: bad argument");
     return o->eng->comm_time_allreduce(n_elements, reps, us_per_call);

@@ -136,12 +136,15 @@ class GraphClient:
         self.sock = socket.create_connection((self.host, self.port))
 
     def _read(self, n):
-        out = b""
-        while len(out) < n:
-            chunk = self.sock.recv(n - len(out))
-            if not chunk:
+        # straight into one buffer of the final size (a 100k-pose reply is 57 MB: appending chunk by chunk copies it several times over)
+        out = bytearray(n)
+        view = memoryview(out)
+        got = 0
+        while got < n:
+            k = self.sock.recv_into(view[got:], n - got)
+            if k == 0:
                 raise ValueError("Connection closed by the server")
-            out += chunk
+            got += k
         return out
 
     def optimize(self, graph):

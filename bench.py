@@ -330,9 +330,10 @@ def main():
     # Sharded runs take the two products INSIDE the multigrid cycle from the replicated explicit level-0 matrix
     # (tsgo_config.cycle_level0 = 1): one all-reduce per PCG iteration instead of three for 6 % more iterations — ahead as soon as an
     # all-reduce costs more than 19 us (profiles/r02e_explicit_level0_in_cycle.txt).  --implicit-cycle keeps the single-device form.
-    explicit_cycle = (shard and not ARGS.implicit_cycle) or ARGS.explicit_cycle
     with watch.phase("synthetic graph"):
         g = synth.make_config(ARGS.workload, seed=0 if shard else rank)
+    # ... and above 500k poses the three products are worth more sharded than two all-reduces cost (24 MB each at a million poses: DESIGN.md section 5)
+    explicit_cycle = (shard and not ARGS.implicit_cycle and g.n_poses <= 500000) or ARGS.explicit_cycle
     n_edges = len(g.e_type)
 
     def make_opt(rank_, world_, explicit_):

@@ -12,6 +12,7 @@ from toyslam_amd.optimizer import HipOptimizer
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 180.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+DEVICES = sys.argv[3] if len(sys.argv) > 3 else None      # e.g. "0,0": the engine pool over a device list (one handle per entry then)
 ITERS = 6
 
 
@@ -35,7 +36,7 @@ def roundtrip(sock, req):
 
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 log = open("/tmp/soak_server.log", "w")
-proc = subprocess.Popen([build.SERVER, "127.0.0.1", str(port), str(ITERS), "gpu", "cuda"], stdout=log, stderr=subprocess.STDOUT)
+proc = subprocess.Popen([build.SERVER, "127.0.0.1", str(port), str(ITERS), "gpu", "cuda"] + (["64", "1e-10", DEVICES, "1"] if DEVICES else []), stdout=log, stderr=subprocess.STDOUT)
 for _ in range(300):
     try:
         socket.create_connection(("127.0.0.1", port), timeout=0.5).close(); break

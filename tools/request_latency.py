@@ -31,7 +31,10 @@ def send(sock, req):
 
 s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
 log = open("/tmp/request_latency_server.log", "w")
-proc = subprocess.Popen([build.SERVER, "127.0.0.1", str(port), iters, "gpu", "cuda"], stdout=log, stderr=subprocess.STDOUT)
+env = dict(os.environ)
+if len(sys.argv) > 3:
+    env["TSGO_WARMUP_POSES"] = sys.argv[3]          # the server's warm-up at the size of the requests to come
+proc = subprocess.Popen([build.SERVER, "127.0.0.1", str(port), iters, "gpu", "cuda"], stdout=log, stderr=subprocess.STDOUT, env=env)
 try:
     for _ in range(300):
         try:

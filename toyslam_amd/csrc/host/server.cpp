@@ -327,7 +327,12 @@ int main(int argc, char* argv[]) {
             {   // one small solve before the first client: loads every kernel's code object and sizes the runtime's pools,
                 // so that the first request does not pay for it (the code objects are per process, not per engine)
                 BlockTimer t{"WarmUp"};
-                tsgo_synth_config sc; sc.n_poses = 2000; sc.lm_per_pose = 8; sc.lm_obs_target = 5.0; sc.loop_closures = 0; sc.seed = 1;
+                // TSGO_WARMUP_POSES: a front-end that knows the size of its graphs lets the warm-up run at that size, so that the device slabs,
+                // the pinned staging and the runtime's pools have their final size before the first request (a 100k-pose first request otherwise
+                // spends ~30 ms growing them)
+                int warm_poses = 2000;
+                if (const char* e = getenv("TSGO_WARMUP_POSES")) warm_poses = std::max(100, std::min(2000000, atoi(e)));
+                tsgo_synth_config sc; sc.n_poses = warm_poses; sc.lm_per_pose = 8; sc.lm_obs_target = 5.0; sc.loop_closures = 0; sc.seed = 1;
                 tsgo_synth* sy = nullptr;
                 if (tsgo_synth_create(&sc, &sy) == 0) {
                     tsgo_graph view; tsgo_synth_view(sy, &view);

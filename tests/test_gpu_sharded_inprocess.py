@@ -107,6 +107,9 @@ def test_bench_probe_sequence_of_a_sharded_run_does_not_deadlock():
             o = HipOptimizer(rank=rank, world=world, pcg_rel_tol=1e-10, testing=True)
             try:
                 o.comm_init_local(group)
+                assert o.comm_selftest() == world                                   # bench.py's order: self-test and all-reduce timing before the graph is set
+                ar_us = [o.comm_time_allreduce(n, reps=3) for n in (3 * 5000 + 40, 18 * 5000 + 40, 1 << 20)]
+                assert min(ar_us) > 0, ar_us
                 o.set_graph(g)
                 chi = [o.optimize(1)["chi2"][0] for _ in range(3)]
                 probes = [o.time_kernel(w, reps=5)[0] for w in (0, 1, 2, 3, 4)]

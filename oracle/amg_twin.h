@@ -192,7 +192,7 @@ struct Hierarchy {
         }
         const AmgLevel& L = sym->levels[l];
         static const int nu_env = getenv("TSGO_TWIN_NU") ? atoi(getenv("TSGO_TWIN_NU")) : 0;
-        const int nu = nu_env ? nu_env : (L.n <= tsgo::kSmallLevelRows ? tsgo::kSmallLevelSweeps : tsgo::kCoarseSweeps);
+        const int nu = nu_env ? nu_env : tsgo::sweeps_per_side((size_t)l, L.n);
         static const int gam = getenv("TSGO_TWIN_GAMMA") ? atoi(getenv("TSGO_TWIN_GAMMA")) : 1;
         dinv_apply(Dinv[l], r[l], z[l], L.n, false, omega[l]);
         for (int s = 1; s < nu; ++s) {

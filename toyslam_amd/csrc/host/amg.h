@@ -40,6 +40,16 @@ constexpr int kCoarseSweeps = 2;      // block-Jacobi sweeps per side on the coa
 constexpr int kSmallLevelRows = 2048; // ... except on levels this small, which get
 constexpr int kSmallLevelSweeps = 1;  // one sweep per side: their kernels are pure launch latency (5 us each) and the second
                                       // sweep buys no iterations there (100k poses, device: 19.6 -> 19.8 PCG iterations, 276 -> 265 us)
+constexpr int kBigLevel1Rows = 8192;  // ... and LEVEL 1 of a graph this large gets one sweep per side as well: it is the most expensive coarse
+                                      // level (two launches of 8 us at 100k poses, 50 us at 1M) and its second sweep buys 0.45 of 15 / 0.5 of 20
+                                      // PCG iterations (round 4, profiles/r04m_sweeps_per_level.txt: 3.55 -> 3.48 ms, 32.2 -> 30.8 ms per step;
+                                      // the same cut on level 2 costs 3.3 iterations; at 10k poses level 1 is small and the cut does not pay)
+// block-Jacobi sweeps per side of the cycle on coarse level l >= 1 with n_rows block rows — ONE rule for the device engine and the CPU twin
+inline int sweeps_per_side(size_t l, int n_rows) {
+    if (n_rows <= kSmallLevelRows) return kSmallLevelSweeps;
+    if (l == 1 && n_rows >= kBigLevel1Rows) return 1;
+    return kCoarseSweeps;
+}
 
 struct BlockCsr {
     int n_rows = 0, n_cols = 0;

@@ -300,7 +300,7 @@ template <typename T> struct Engine : IEngine {
     std::vector<int> sweeps_list;      // research: sweeps per side on levels 1, 2, ... (TSGO_SWEEPS_LIST="2,2,1"; the last entry repeats)
     int nu_at(size_t l) const {
         if (!sweeps_list.empty()) return sweeps_list[std::min(l - 1, sweeps_list.size() - 1)];
-        return lv[l].n <= kSmallLevelRows ? kSmallLevelSweeps : coarse_sweeps;
+        return coarse_sweeps != kCoarseSweeps ? (lv[l].n <= kSmallLevelRows ? kSmallLevelSweeps : coarse_sweeps) : sweeps_per_side(l, lv[l].n);
     }
     bool low_cycle = true;     // f32 slot planes for the Schur products inside the multigrid cycle
     bool cy16 = true;          // the cycle-format copies of A_l, P_l, R_l as packed half floats (20 B per block) or f32 (36 B): tsgo_config.cycle_storage,

@@ -75,7 +75,9 @@ while time.time() < t_end:
             barw = 1e-6 * max(1.0, rw["delta_norm"] / 1e4) * (max(1.0, float(np.abs(refw["v_pos"]).max()) / 100.0) if oj == "analytic" else 1.0)
             divw = refw["stop"] == "worse" or refw["chi2"][-1] > refw["chi2"][0]
             beamw = shape.startswith("pose graph") and oj == "analytic"
-            okw = rw["iters"] == refw["iters"] and rw["stop"] == refw["stop"] and np.allclose(rw["chi2"], refw["chi2"], rtol=1e-6 if (divw or beamw) else 1e-8) \
+            hardw = divw and max(rw["cg_iters"]) > 300      # a DIVERGING run through solves of hundreds of iterations (two landmarks per pose under full Python-rule steps): two device runs of the
+                                                          # same request at 1e-11 / 1e-13 end 6 apart, chi^2 2e-4 apart (profiles/r04o_soak_seed101_trial7_replay.txt)
+            okw = rw["iters"] == refw["iters"] and rw["stop"] == refw["stop"] and np.allclose(rw["chi2"], refw["chi2"], rtol=1e-3 if hardw else (1e-6 if (divw or beamw) else 1e-8)) \
                 and (divw or dw < (1e-4 if beamw else barw))      # a diverging run (chi^2 rising: pose graphs under the constant Jacobians) is compared by its chi^2 only: two twin runs at 1e-12 / 1e-14 end 4e-4 apart there (profiles/r03y_soak_trial52_replay.log)
             print("          second request with the returned estimates (history carried: first %d, second %d): GN %d/%d stop %s/%s  cg %s (twin %s)  max vertex diff %.2e  %s"
                   % (rw0["history_carried"], rw["history_carried"], rw["iters"], refw["iters"], rw["stop"], refw["stop"], list(map(int, rw["cg_iters"])), list(map(int, refw["cg_iters"])), dw, "ok" if okw else "MISMATCH"), flush=True)

@@ -242,3 +242,24 @@ def test_c3_two_sharded_iterations_followed_step_by_step_by_the_numpy_checker():
         for o in hs:
             o.close()
         free_local_group(group)
+
+
+def test_a_cycle_left_indefinite_by_the_f32_hierarchy_is_cured_without_falling_back_to_block_jacobi():
+    """372 657 poses sent again with the estimates that came back (f32): for the first linearisations of that second request the hierarchy's
+    level-0 matrix — S rounded to f32 — is indefinite in the map's smooth modes, the cycle with it, and PCG breaks down with r^T M^-1 r < 0
+    (profiles/r04p_indefinite_cycle_f32_hierarchy.txt; until the end of round 4 three or four solves then fell back to 15 500 block-Jacobi
+    iterations each).  The engine raises the diagonal of the hierarchy's copy of S by 1e-6 and solves again with the multigrid cycle."""
+    from toyslam_amd.graph import GraphArrays
+    g = synth.make(372657, 7, loop_closures=5508, seed=619541)
+    g.fixed = np.array([0], np.uint32)
+    o = HipOptimizer(pcg_rel_tol=1e-11, odom_jacobian="analytic", warm_requests=True)
+    try:
+        o.set_graph(g); r1 = o.optimize(12); v1 = o.vertices()
+        g2 = GraphArrays(g.v_id, g.v_type, v1.astype(np.float32).astype(np.float64), g.e_type, g.e_ids, g.e_meas, g.e_inf, g.fixed)
+        o.set_graph(g2); r2 = o.optimize(12)
+    finally:
+        o.close()
+    assert r1["fallbacks"] == 0 and r2["fallbacks"] == 0
+    assert r2["structure_reused"] and r2["history_carried"] == 1
+    assert max(r2["cg_iters"]) < 200, r2["cg_iters"]            # 42 ... 65 with the raised diagonal; 15 500 was the fallback
+    assert np.all(np.diff(r2["chi2"]) < 0) and r2["chi2"][-1] < 0.2 * r2["chi2"][0]

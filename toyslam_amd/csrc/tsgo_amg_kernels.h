@@ -86,7 +86,7 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
                                                          size_t od_slots, const T* __restrict__ lmrec, const T* __restrict__ ps,
                                                          const T* __restrict__ part, HT<T>* __restrict__ A, int diag_on,
                                                          const uint32_t* __restrict__ od_idx, int odom_analytic, const int* __restrict__ which,
-                                                         const int* __restrict__ lower_of) {
+                                                         const int* __restrict__ lower_of, T diag_shift = T(0)) {
     const int t = blockIdx.x * kBlock + threadIdx.x;
     if (t >= nnz) return;
     const int b = which ? which[t] : t;      // which: the blocks on or above the diagonal; S is symmetric: each also writes its mirror (lower_of)
@@ -100,7 +100,8 @@ __global__ __launch_bounds__(kBlock) void k_schur_blocks(int nnz, const int* __r
         }
         const T* p = part + (size_t)i * 18;
         const T m0 = p[0] - p[9], m1 = p[1] - p[10], m2 = p[2] - p[11], m3 = p[3] - p[12], m4 = p[4] - p[13], m5 = p[5] - p[14];
-        o[0] = m0; o[1] = m1; o[2] = m2; o[3] = m1; o[4] = m3; o[5] = m4; o[6] = m2; o[7] = m4; o[8] = m5;
+        const T up = T(1) + diag_shift;      // (engine: hier_shift) the hierarchy's copy of S with its diagonal raised: positive definite again where f32 rounding left it indefinite
+        o[0] = m0 * up; o[1] = m1; o[2] = m2; o[3] = m1; o[4] = m3 * up; o[5] = m4; o[6] = m2; o[7] = m4; o[8] = m5 * up;
         return;
     }
     const T ci = ps[(size_t)i * 4 + 2], si = ps[(size_t)i * 4 + 3], ck = ps[(size_t)k * 4 + 2], sk = ps[(size_t)k * 4 + 3];

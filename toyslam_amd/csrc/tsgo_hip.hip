@@ -251,6 +251,8 @@ template <typename T> struct Engine : IEngine {
     T* h_scratch = nullptr;            // pinned, partial sums
     int nbP = 0, nbL = 0, nbC = 0;
     bool fuse_post_smooth = true;      // the level-0 post-smoothing in the epilogue of the cycle's second product (research: TSGO_FUSE_POST=0 = k_smooth0)
+    double hier_shift_cfg = 0;         // what a graph starts with (0; research: TSGO_HIER_SHIFT)
+    double hier_shift = 0;             // relative raise of the diagonal of the hierarchy's level-0 matrix (research: TSGO_HIER_SHIFT; do_solve sets it after a breakdown)
     bool fold_gate = true;             // the stopping rule in workgroup 0 of the iteration's first product (research: TSGO_FOLD_GATE=0 = its own kernel)
     hipGraphExec_t cg_graph = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -329,6 +331,7 @@ template <typename T> struct Engine : IEngine {
         if (const char* e = TSGO_RESEARCH_ENV("TSGO_PACE_LEAD")) pace_lead = std::max(1, atoi(e));
         if (const char* e = TSGO_RESEARCH_ENV("TSGO_LPR_XCD")) lpr_xcd = atoi(e) != 0;
         if (const char* e = TSGO_RESEARCH_ENV("TSGO_FOLD_GATE")) fold_gate = atoi(e) != 0;
+        if (const char* e = TSGO_RESEARCH_ENV("TSGO_HIER_SHIFT")) hier_shift = hier_shift_cfg = atof(e);
         if (const char* e = TSGO_RESEARCH_ENV("TSGO_FUSE_POST")) fuse_post_smooth = atoi(e) != 0;
         hook_inject_amg_failure = TSGO_RESEARCH_ENV("TSGO_INJECT_AMG_FAILURE") != nullptr;
         hook_force_host_slow = TSGO_RESEARCH_ENV("TSGO_FORCE_HOST_SLOW") != nullptr;
